@@ -1,0 +1,96 @@
+"""
+ctypes binding of libfep_hip.so (C ABI: include/fep.h).  There is NO fallback: if the HIP
+library is missing, or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_i32_p = C.POINTER(C.c_int32)
+c_i64_p = C.POINTER(C.c_int64)
+c_u8_p = C.POINTER(C.c_uint8)
+c_void_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); the complete export list of include/fep.h
+PROTOTYPES = {
+    'fep_version': (C.c_int, []),
+    'fep_strerror': (C.c_char_p, [C.c_int]),
+    'fep_last_hip_error': (C.c_int, []),
+    'fep_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'fep_element_shape': (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'fep_malloc': (C.c_int, [C.c_int, c_void_pp, C.c_int64]),
+    'fep_free': (C.c_int, [C.c_int, C.c_void_p]),
+    'fep_memcpy_h2d': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
+    'fep_memcpy_d2h': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
+    'fep_sync': (C.c_int, [C.c_int, C.c_void_p]),
+    'fep_return_map_host': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_return_map_dev': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_ctx_create': (C.c_int, [c_void_pp, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_ctx_destroy': (C.c_int, [C.c_void_p]),
+    'fep_ctx_sizes': (C.c_int, [C.c_void_p, c_i64_p]),
+    'fep_ctx_geometry_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_ctx_pattern_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_ctx_set_materials_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_ctx_device_ptr': (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
+    'fep_step_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_step_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_assemble_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_assemble_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_step_kernel_names': (C.c_char_p, [C.c_void_p]),
+    'fep_step_kernel_time': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+
+class FepError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        l = lib()
+        msg = l.fep_strerror(code).decode()
+        if code == -4:
+            msg += f' (hipError_t {l.fep_last_hip_error()})'
+        super().__init__(f'{where}: {msg} [{code}]')
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """The loaded library.  Raises ImportError when it has not been built
+    (`python __graft_entry__.py build` / `fem-elastoplasticity_amd/build.py`)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(f'{path} is missing: the HIP extension has not been built '
+                              f'(run `python -c "import __graft_entry__ as g; g.build()"`). '
+                              f'There is no CPU fallback.')
+        l = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def check(code, where):
+    if code != 0:
+        raise FepError(code, where)
+
+
+def ptr(a):
+    """void* of a NumPy array (or None)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,46 @@
+"""
+Builds csrc/libfep_hip.so (HIP kernels + C ABI, include/fep.h) in-tree with hipcc for gfx950.
+hipcc cross-compiles without a GPU.  Used by __graft_entry__.build() and by `python -m`.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libfep_hip.so')
+SOURCES = ['fep_api.hip']
+DEPS = ['fep_api.hip', 'fep_kernels.hip.h', os.path.join('..', '..', 'include', 'fep.h')]
+
+
+def hipcc_path():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (set HIPCC or put /opt/rocm/bin on PATH)')
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    """Compile the shared library if it is missing or older than its sources."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-o', LIB + '.tmp'] + SOURCES
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError('hipcc failed:\n' + res.stdout)
+    os.replace(LIB + '.tmp', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,626 @@
+// C-ABI implementation of include/fep.h (libfep_hip.so).  Host side: context, symbolic
+// phase (node graph -> CSR pattern + gather lists), launches.  Device side: fep_kernels.hip.h.
+#include "../../include/fep.h"
+#include "fep_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+using namespace fep;
+
+static thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) {                         \
+            g_last_hip = (int)_e;                       \
+            (void)hipGetLastError();                    \
+            return _e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; \
+        }                                               \
+    } while (0)
+#define FEP_TRY(expr)                  \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != FEP_OK) return _r;   \
+    } while (0)
+
+struct fep_ctx {
+    int device = 0;
+    int elem_type = 0;
+    int n_p = 0, n_q = 0;
+    int64_t n_e = 0, n_n = 0, n_int = 0, n_dof = 0, nnz = 0, n_blk = 0, n_contrib = 0;
+    bool have_materials = false;
+    // device, static
+    int32_t* elem = nullptr;
+    double *coords = nullptr, *dh1 = nullptr, *dh2 = nullptr, *wf = nullptr;
+    double *dphi1 = nullptr, *dphi2 = nullptr, *weight = nullptr, *det = nullptr;
+    double *shear = nullptr, *bulk = nullptr, *eta = nullptr, *c = nullptr;
+    int32_t *segptr = nullptr, *perm = nullptr, *iptr = nullptr, *ilist = nullptr;
+    uint32_t* meta = nullptr;
+    // device, scratch rewritten by every step
+    double *Kc = nullptr, *fe = nullptr;
+    unsigned long long* counts = nullptr;
+    // host copies of the pattern
+    std::vector<int32_t> indptr, indices;
+};
+
+static int set_device(int dev) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_last_hip = (int)e; (void)hipGetLastError(); return FEP_ENODEV; }
+    if (dev < 0 || dev >= n) return FEP_ENODEV;
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) { g_last_hip = (int)e; (void)hipGetLastError(); return FEP_ENODEV; }
+    return FEP_OK;
+}
+
+template <class T> static int dmalloc(T** p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    HIP_TRY(hipMalloc((void**)p, (size_t)count * sizeof(T)));
+    return FEP_OK;
+}
+template <class T> static int upload(T** p, const T* src, int64_t count) {
+    FEP_TRY(dmalloc(p, count));
+    if (count > 0) HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
+    return FEP_OK;
+}
+
+// RAII for temporary device buffers of the *_host entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(int64_t bytes) { HIP_TRY(hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 1))); return FEP_OK; }
+    int from(const void* h, int64_t bytes) {
+        FEP_TRY(alloc(bytes));
+        if (bytes > 0) HIP_TRY(hipMemcpy(p, h, (size_t)bytes, hipMemcpyHostToDevice));
+        return FEP_OK;
+    }
+    int to(void* h, int64_t bytes) const {
+        if (bytes > 0) HIP_TRY(hipMemcpy(h, p, (size_t)bytes, hipMemcpyDeviceToHost));
+        return FEP_OK;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+static inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ---------------------------------------------------------------------------------------
+extern "C" int fep_version(void) { return 1; }
+
+extern "C" const char* fep_strerror(int code) {
+    switch (code) {
+        case FEP_OK: return "ok";
+        case FEP_EINVAL: return "invalid argument";
+        case FEP_ENODEV: return "no usable HIP device";
+        case FEP_ENOMEM: return "out of memory";
+        case FEP_EHIP: return "HIP runtime error";
+        case FEP_ERANGE: return "index out of range";
+        case FEP_ESTATE: return "call order violated";
+        default: return "unknown error";
+    }
+}
+extern "C" int fep_last_hip_error(void) { return g_last_hip; }
+
+extern "C" int fep_device_count(int* n_out) {
+    if (!n_out) return FEP_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_last_hip = (int)e; (void)hipGetLastError(); *n_out = 0; return FEP_ENODEV; }
+    *n_out = n;
+    return FEP_OK;
+}
+
+extern "C" int fep_element_shape(int elem_type, int* n_p, int* n_q) {
+    int p, q;
+    switch (elem_type) {
+        case FEP_P1: p = 3; q = 1; break;
+        case FEP_P2: p = 6; q = 7; break;
+        case FEP_Q1: p = 4; q = 4; break;
+        case FEP_Q2: p = 8; q = 9; break;
+        case FEP_P4: p = 15; q = 12; break;
+        default: return FEP_EINVAL;
+    }
+    if (n_p) *n_p = p;
+    if (n_q) *n_q = q;
+    return FEP_OK;
+}
+
+extern "C" int fep_malloc(int device_id, void** ptr_d, int64_t bytes) {
+    if (!ptr_d || bytes < 0) return FEP_EINVAL;
+    FEP_TRY(set_device(device_id));
+    HIP_TRY(hipMalloc(ptr_d, (size_t)(bytes > 0 ? bytes : 1)));
+    return FEP_OK;
+}
+extern "C" int fep_free(int device_id, void* ptr_d) {
+    if (!ptr_d) return FEP_OK;
+    FEP_TRY(set_device(device_id));
+    HIP_TRY(hipFree(ptr_d));
+    return FEP_OK;
+}
+extern "C" int fep_memcpy_h2d(int device_id, void* dst_d, const void* src_h, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst_d || !src_h))) return FEP_EINVAL;
+    FEP_TRY(set_device(device_id));
+    if (bytes) HIP_TRY(hipMemcpy(dst_d, src_h, (size_t)bytes, hipMemcpyHostToDevice));
+    return FEP_OK;
+}
+extern "C" int fep_memcpy_d2h(int device_id, void* dst_h, const void* src_d, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst_h || !src_d))) return FEP_EINVAL;
+    FEP_TRY(set_device(device_id));
+    if (bytes) HIP_TRY(hipMemcpy(dst_h, src_d, (size_t)bytes, hipMemcpyDeviceToHost));
+    return FEP_OK;
+}
+extern "C" int fep_sync(int device_id, void* stream) {
+    FEP_TRY(set_device(device_id));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return FEP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// a2 mesh-free
+// ---------------------------------------------------------------------------------------
+static E0 make_e0(const double* e0_h) {
+    E0 z;
+    for (int i = 0; i < 4; ++i) z.v[i] = e0_h ? e0_h[i] : 0.0;
+    return z;
+}
+
+extern "C" int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
+                                  const double* e_d, int64_t e_pt_stride, int64_t e_comp_stride,
+                                  const double* e0_h, double* ep_prev_d,
+                                  const double* shear_d, const double* bulk_d, const double* eta_d, const double* c_d,
+                                  int accept, double* s_d, double* ds_d, uint8_t* ind_p_d, int64_t* counts_d) {
+    if (n_int < 0) return FEP_EINVAL;
+    if (n_int > 0 && (!e_d || !shear_d || !bulk_d || !eta_d || !c_d)) return FEP_EINVAL;
+    FEP_TRY(set_device(device_id));
+    hipStream_t st = (hipStream_t)stream;
+    if (counts_d) HIP_TRY(hipMemsetAsync(counts_d, 0, 2 * sizeof(int64_t), st));
+    if (n_int == 0) return FEP_OK;
+    hipLaunchKernelGGL(return_map_kernel, dim3(grid_for(n_int, kBlock)), dim3(kBlock), 0, st,
+                       n_int, e_d, e_pt_stride, e_comp_stride, make_e0(e0_h), ep_prev_d,
+                       shear_d, bulk_d, eta_d, c_d, accept, s_d, ds_d, ind_p_d, (unsigned long long*)counts_d);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+extern "C" int fep_return_map_host(int device_id, int64_t n_int,
+                                   const double* e_h, int64_t e_pt_stride, int64_t e_comp_stride,
+                                   const double* e0_h, double* ep_prev_h,
+                                   const double* shear_h, const double* bulk_h, const double* eta_h, const double* c_h,
+                                   int accept, double* s_h, double* ds_h, uint8_t* ind_p_h, int64_t* counts_h) {
+    if (n_int < 0) return FEP_EINVAL;
+    if (n_int > 0 && (!e_h || !shear_h || !bulk_h || !eta_h || !c_h)) return FEP_EINVAL;
+    if (counts_h) { counts_h[0] = 0; counts_h[1] = 0; }
+    if (n_int == 0) return FEP_OK;
+    FEP_TRY(set_device(device_id));
+    // the strain is copied as the dense block that contains the strided view
+    const int64_t span = (n_int - 1) * e_pt_stride + 2 * e_comp_stride + 1;
+    if (e_pt_stride <= 0 || e_comp_stride <= 0 || span < 3 * n_int) return FEP_EINVAL;
+    const int64_t nb = n_int * (int64_t)sizeof(double);
+    DevBuf e, ep, sh, bu, et, cc, s, ds, ip, cnt;
+    FEP_TRY(e.from(e_h, span * (int64_t)sizeof(double)));
+    if (ep_prev_h) FEP_TRY(ep.from(ep_prev_h, 4 * nb));
+    FEP_TRY(sh.from(shear_h, nb)); FEP_TRY(bu.from(bulk_h, nb)); FEP_TRY(et.from(eta_h, nb)); FEP_TRY(cc.from(c_h, nb));
+    if (s_h) FEP_TRY(s.alloc(4 * nb));
+    if (ds_h) FEP_TRY(ds.alloc(9 * nb));
+    if (ind_p_h) FEP_TRY(ip.alloc(n_int));
+    FEP_TRY(cnt.alloc(2 * sizeof(int64_t)));
+    FEP_TRY(fep_return_map_dev(device_id, nullptr, n_int, e.as<double>(), e_pt_stride, e_comp_stride, e0_h,
+                               ep.as<double>(), sh.as<double>(), bu.as<double>(), et.as<double>(), cc.as<double>(),
+                               accept, s.as<double>(), ds.as<double>(), ip.as<uint8_t>(), cnt.as<int64_t>()));
+    HIP_TRY(hipDeviceSynchronize());
+    if (s_h) FEP_TRY(s.to(s_h, 4 * nb));
+    if (ds_h) FEP_TRY(ds.to(ds_h, 9 * nb));
+    if (ind_p_h) FEP_TRY(ip.to(ind_p_h, n_int));
+    if (counts_h) FEP_TRY(cnt.to(counts_h, 2 * sizeof(int64_t)));
+    if (accept && ep_prev_h) FEP_TRY(ep.to(ep_prev_h, 4 * nb));
+    return FEP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Symbolic phase (host).  Node graph of the mesh -> (i) CSR pattern of K on DOFs,
+// (ii) per node-pair block the list of element-local blocks that sum into it,
+// (iii) per node the list of (element, local node) pairs for the force gather.
+// ---------------------------------------------------------------------------------------
+struct Symbolic {
+    std::vector<int32_t> iptr, ilist;        // node -> incident (a*n_e + e), ordered by (e, a)
+    std::vector<int32_t> nptr, ncol;         // node CSR (sorted neighbour nodes)
+    std::vector<int32_t> segptr, perm;       // block -> contributions (a*NP+b)*n_e + e
+    std::vector<uint32_t> meta;              // block -> (deg << 16) | slot
+};
+
+
+static int build_symbolic(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem, Symbolic& S) {
+    if ((int64_t)n_p * n_p * n_e >= (int64_t)INT32_MAX / 2) return FEP_ERANGE;
+    for (int64_t i = 0; i < (int64_t)n_p * n_e; ++i)
+        if (elem[i] < 0 || elem[i] >= n_n) return FEP_ERANGE;
+    // (iii) incidence lists
+    S.iptr.assign(n_n + 1, 0);
+    for (int64_t i = 0; i < (int64_t)n_p * n_e; ++i) S.iptr[elem[i] + 1]++;
+    for (int64_t n = 0; n < n_n; ++n) S.iptr[n + 1] += S.iptr[n];
+    S.ilist.resize(S.iptr[n_n]);
+    {
+        std::vector<int32_t> fill(S.iptr.begin(), S.iptr.end() - 1);
+        for (int64_t e = 0; e < n_e; ++e)
+            for (int a = 0; a < n_p; ++a) S.ilist[fill[elem[(int64_t)a * n_e + e]]++] = (int32_t)((int64_t)a * n_e + e);
+    }
+    // (i)+(ii) per node: gather (neighbour, code) pairs, sort by neighbour (stable in (e,a,b) order)
+    const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<int32_t> deg(n_n, 0);
+    auto node_pairs = [&](int64_t n, std::vector<std::pair<int32_t, int32_t>>& buf) {
+        buf.clear();
+        for (int32_t t = S.iptr[n]; t < S.iptr[n + 1]; ++t) {
+            const int64_t code = S.ilist[t];
+            const int a = (int)(code / n_e);
+            const int64_t e = code - (int64_t)a * n_e;
+            for (int b = 0; b < n_p; ++b)
+                buf.emplace_back(elem[(int64_t)b * n_e + e], (int32_t)(((int64_t)a * n_p + b) * n_e + e));
+        }
+        std::stable_sort(buf.begin(), buf.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    };
+    // pass 1: degrees
+    {
+        std::vector<std::thread> th;
+        for (int w = 0; w < nthreads; ++w)
+            th.emplace_back([&, w]() {
+                std::vector<std::pair<int32_t, int32_t>> buf;
+                for (int64_t n = n_n * w / nthreads; n < n_n * (w + 1) / nthreads; ++n) {
+                    node_pairs(n, buf);
+                    int32_t d = 0;
+                    for (size_t i = 0; i < buf.size(); ++i)
+                        if (i == 0 || buf[i].first != buf[i - 1].first) ++d;
+                    deg[n] = d;
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    S.nptr.assign(n_n + 1, 0);
+    int64_t tot = 0;
+    for (int64_t n = 0; n < n_n; ++n) {
+        if (deg[n] > 0xffff) return FEP_ERANGE;
+        tot += deg[n];
+        if (tot >= INT32_MAX / 4) return FEP_ERANGE;
+        S.nptr[n + 1] = (int32_t)tot;
+    }
+    const int64_t n_blk = tot;
+    const int64_t n_contrib = (int64_t)n_p * n_p * n_e;
+    S.ncol.resize(n_blk);
+    S.meta.resize(n_blk);
+    S.segptr.assign(n_blk + 1, 0);
+    S.perm.resize(n_contrib);
+    // contributions of node n start at n_p * iptr[n] (each incident (e,a) brings n_p pairs)
+    {
+        std::vector<std::thread> th;
+        for (int w = 0; w < nthreads; ++w)
+            th.emplace_back([&, w]() {
+                std::vector<std::pair<int32_t, int32_t>> buf;
+                for (int64_t n = n_n * w / nthreads; n < n_n * (w + 1) / nthreads; ++n) {
+                    node_pairs(n, buf);
+                    int64_t pos = (int64_t)n_p * S.iptr[n];
+                    int32_t slot = -1;
+                    for (size_t i = 0; i < buf.size(); ++i) {
+                        if (i == 0 || buf[i].first != buf[i - 1].first) {
+                            ++slot;
+                            const int64_t blk = S.nptr[n] + slot;
+                            S.ncol[blk] = buf[i].first;
+                            S.meta[blk] = ((uint32_t)deg[n] << 16) | (uint32_t)slot;
+                            S.segptr[blk] = (int32_t)pos;
+                        }
+                        S.perm[pos++] = buf[i].second;
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    S.segptr[n_blk] = (int32_t)n_contrib;
+    return FEP_OK;
+}
+
+template <int NP, int NQ>
+static int launch_geometry(fep_ctx* c) {
+    hipLaunchKernelGGL((geometry_kernel<NP, NQ>), dim3(grid_for(c->n_int, kBlock)), dim3(kBlock), 0, nullptr,
+                       c->n_e, c->n_n, c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+#define DISPATCH_ELEM(type, CALL)                    \
+    switch (type) {                                  \
+        case FEP_P1: { CALL(3, 1); } break;          \
+        case FEP_P2: { CALL(6, 7); } break;          \
+        case FEP_Q1: { CALL(4, 4); } break;          \
+        case FEP_Q2: { CALL(8, 9); } break;          \
+        case FEP_P4: { CALL(15, 12); } break;        \
+        default: return FEP_EINVAL;                  \
+    }
+
+extern "C" int fep_ctx_destroy(fep_ctx* c) {
+    if (!c) return FEP_OK;
+    if (set_device(c->device) == FEP_OK) {
+        void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
+                        c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->counts};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    delete c;
+    return FEP_OK;
+}
+
+extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, int64_t n_e, int64_t n_n,
+                              const int32_t* elements_h, const double* coords_h,
+                              const double* dhatp1_h, const double* dhatp2_h, const double* wf_h) {
+    if (!ctx_out) return FEP_EINVAL;
+    *ctx_out = nullptr;
+    int n_p = 0, n_q = 0;
+    FEP_TRY(fep_element_shape(elem_type, &n_p, &n_q));
+    if (n_e <= 0 || n_n <= 0 || !elements_h || !coords_h || !dhatp1_h || !dhatp2_h || !wf_h) return FEP_EINVAL;
+    if (n_e * (int64_t)n_q >= INT32_MAX / 16) return FEP_ERANGE;
+    Symbolic S;
+    FEP_TRY(build_symbolic(n_p, n_e, n_n, elements_h, S));
+    FEP_TRY(set_device(device_id));
+    fep_ctx* c = new (std::nothrow) fep_ctx();
+    if (!c) return FEP_ENOMEM;
+    c->device = device_id; c->elem_type = elem_type; c->n_p = n_p; c->n_q = n_q;
+    c->n_e = n_e; c->n_n = n_n; c->n_int = n_e * n_q; c->n_dof = 2 * n_n;
+    c->n_blk = (int64_t)S.ncol.size(); c->nnz = 4 * c->n_blk; c->n_contrib = (int64_t)S.perm.size();
+    // host CSR pattern on DOFs
+    c->indptr.resize(c->n_dof + 1);
+    c->indices.resize(c->nnz);
+    for (int64_t n = 0; n < n_n; ++n) {
+        const int64_t d = S.nptr[n + 1] - S.nptr[n];
+        for (int i = 0; i < 2; ++i) {
+            const int64_t start = 4 * (int64_t)S.nptr[n] + i * 2 * d;
+            c->indptr[2 * n + i] = (int32_t)start;
+            for (int64_t s = 0; s < d; ++s) {
+                c->indices[start + 2 * s] = 2 * S.ncol[S.nptr[n] + s];
+                c->indices[start + 2 * s + 1] = 2 * S.ncol[S.nptr[n] + s] + 1;
+            }
+        }
+    }
+    c->indptr[c->n_dof] = (int32_t)c->nnz;
+    int r = FEP_OK;
+#define CK(x) if (r == FEP_OK) r = (x)
+    CK(upload(&c->elem, elements_h, (int64_t)n_p * n_e));
+    CK(upload(&c->coords, coords_h, 2 * n_n));
+    CK(upload(&c->dh1, dhatp1_h, (int64_t)n_p * n_q));
+    CK(upload(&c->dh2, dhatp2_h, (int64_t)n_p * n_q));
+    CK(upload(&c->wf, wf_h, (int64_t)n_q));
+    CK(dmalloc(&c->dphi1, (int64_t)n_p * c->n_int));
+    CK(dmalloc(&c->dphi2, (int64_t)n_p * c->n_int));
+    CK(dmalloc(&c->weight, c->n_int));
+    CK(dmalloc(&c->det, c->n_int));
+    CK(dmalloc(&c->shear, c->n_int)); CK(dmalloc(&c->bulk, c->n_int)); CK(dmalloc(&c->eta, c->n_int)); CK(dmalloc(&c->c, c->n_int));
+    CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
+    CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
+    CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
+    CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
+    CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
+    CK(dmalloc(&c->Kc, 4 * c->n_contrib));
+    CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
+    CK(dmalloc(&c->counts, 2));
+#undef CK
+    if (r == FEP_OK) {
+#define CALL(NP, NQ) r = launch_geometry<NP, NQ>(c)
+        switch (elem_type) {
+            case FEP_P1: CALL(3, 1); break;
+            case FEP_P2: CALL(6, 7); break;
+            case FEP_Q1: CALL(4, 4); break;
+            case FEP_Q2: CALL(8, 9); break;
+            case FEP_P4: CALL(15, 12); break;
+        }
+#undef CALL
+    }
+    if (r == FEP_OK && hipDeviceSynchronize() != hipSuccess) { g_last_hip = (int)hipGetLastError(); r = FEP_EHIP; }
+    if (r != FEP_OK) { fep_ctx_destroy(c); return r; }
+    *ctx_out = c;
+    return FEP_OK;
+}
+
+extern "C" int fep_ctx_sizes(const fep_ctx* c, int64_t sizes[8]) {
+    if (!c || !sizes) return FEP_EINVAL;
+    sizes[0] = c->n_e; sizes[1] = c->n_n; sizes[2] = c->n_p; sizes[3] = c->n_q;
+    sizes[4] = c->n_int; sizes[5] = c->n_dof; sizes[6] = c->nnz; sizes[7] = c->n_blk;
+    return FEP_OK;
+}
+
+extern "C" int fep_ctx_geometry_host(fep_ctx* c, double* dphi1_h, double* dphi2_h, double* weight_h, double* det_h) {
+    if (!c) return FEP_EINVAL;
+    FEP_TRY(set_device(c->device));
+    const size_t nb = (size_t)c->n_int * sizeof(double);
+    if (dphi1_h) HIP_TRY(hipMemcpy(dphi1_h, c->dphi1, nb * c->n_p, hipMemcpyDeviceToHost));
+    if (dphi2_h) HIP_TRY(hipMemcpy(dphi2_h, c->dphi2, nb * c->n_p, hipMemcpyDeviceToHost));
+    if (weight_h) HIP_TRY(hipMemcpy(weight_h, c->weight, nb, hipMemcpyDeviceToHost));
+    if (det_h) HIP_TRY(hipMemcpy(det_h, c->det, nb, hipMemcpyDeviceToHost));
+    return FEP_OK;
+}
+
+extern "C" int fep_ctx_pattern_host(const fep_ctx* c, int32_t* indptr_h, int32_t* indices_h) {
+    if (!c) return FEP_EINVAL;
+    if (indptr_h) std::memcpy(indptr_h, c->indptr.data(), c->indptr.size() * sizeof(int32_t));
+    if (indices_h) std::memcpy(indices_h, c->indices.data(), c->indices.size() * sizeof(int32_t));
+    return FEP_OK;
+}
+
+extern "C" int fep_ctx_set_materials_host(fep_ctx* c, const double* shear_h, const double* bulk_h,
+                                          const double* eta_h, const double* c_h) {
+    if (!c || !shear_h || !bulk_h || !eta_h || !c_h) return FEP_EINVAL;
+    FEP_TRY(set_device(c->device));
+    const size_t nb = (size_t)c->n_int * sizeof(double);
+    HIP_TRY(hipMemcpy(c->shear, shear_h, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->bulk, bulk_h, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->eta, eta_h, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->c, c_h, nb, hipMemcpyHostToDevice));
+    c->have_materials = true;
+    return FEP_OK;
+}
+
+extern "C" int fep_ctx_device_ptr(const fep_ctx* c, int which, void** ptr_d) {
+    if (!c || !ptr_d) return FEP_EINVAL;
+    switch (which) {
+        case 0: *ptr_d = c->shear; break;
+        case 1: *ptr_d = c->bulk; break;
+        case 2: *ptr_d = c->eta; break;
+        case 3: *ptr_d = c->c; break;
+        case 4: *ptr_d = c->weight; break;
+        case 5: *ptr_d = c->dphi1; break;
+        case 6: *ptr_d = c->dphi2; break;
+        default: return FEP_EINVAL;
+    }
+    return FEP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// hot path
+// ---------------------------------------------------------------------------------------
+template <int NP, int NQ, bool FROM_U>
+static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept,
+                          double* eout, double* s, double* ds, uint8_t* indp, unsigned long long* counts,
+                          double* Kc, double* fe) {
+    constexpr int EB = ElemCfg<NP, NQ>::EB;
+    static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
+    hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U>), dim3(grid_for(c->n_e, EB)), dim3(kBlock), 0, st,
+                       c->n_e, c->elem, c->dphi1, c->dphi2, c->weight, u, e0, ep, c->shear, c->bulk, c->eta, c->c,
+                       accept, eout, s, ds, indp, counts, Kc, fe);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_out) {
+    if (k_data) {
+        hipLaunchKernelGGL(csr_reduce_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
+                           c->n_blk, c->segptr, c->perm, c->meta, c->Kc, k_data);
+        HIP_TRY(hipGetLastError());
+    }
+    if (f_out) {
+        hipLaunchKernelGGL(force_reduce_kernel, dim3(grid_for(c->n_n, kBlock)), dim3(kBlock), 0, st,
+                           c->n_n, c->iptr, c->ilist, c->fe, f_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return FEP_OK;
+}
+
+extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const double* e0_h,
+                            double* ep_prev_d, int accept, double* e_out_d, double* s_d, double* ds_d,
+                            uint8_t* ind_p_d, double* k_data_d, double* f_out_d, int64_t* counts_d) {
+    if (!c || !u_d) return FEP_EINVAL;
+    if (!c->have_materials) return FEP_ESTATE;
+    FEP_TRY(set_device(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* cnt = (unsigned long long*)counts_d;
+    if (cnt) HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int64_t), st));
+    const E0 e0 = make_e0(e0_h);
+#define CALL(NP, NQ)                                                                                     \
+    FEP_TRY((launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, cnt, \
+                                          k_data_d ? c->Kc : nullptr, f_out_d ? c->fe : nullptr)))
+    DISPATCH_ELEM(c->elem_type, CALL)
+#undef CALL
+    return launch_reduce(c, st, k_data_d, f_out_d);
+}
+
+extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, const double* s_d,
+                                double* k_data_d, double* f_out_d) {
+    if (!c) return FEP_EINVAL;
+    if ((k_data_d && !ds_d) || (f_out_d && !s_d)) return FEP_EINVAL;
+    FEP_TRY(set_device(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const E0 e0 = make_e0(nullptr);
+#define CALL(NP, NQ)                                                                                         \
+    FEP_TRY((launch_element<NP, NQ, false>(c, st, nullptr, e0, nullptr, 0, nullptr, const_cast<double*>(s_d), \
+                                           const_cast<double*>(ds_d), nullptr, nullptr,                      \
+                                           k_data_d ? c->Kc : nullptr, f_out_d ? c->fe : nullptr)))
+    DISPATCH_ELEM(c->elem_type, CALL)
+#undef CALL
+    return launch_reduce(c, st, k_data_d, f_out_d);
+}
+
+extern "C" int fep_step_host(fep_ctx* c, const double* u_h, const double* e0_h, double* ep_prev_h, int accept,
+                             double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
+                             double* k_data_h, double* f_out_h, int64_t* counts_h) {
+    if (!c || !u_h) return FEP_EINVAL;
+    FEP_TRY(set_device(c->device));
+    const int64_t nb = c->n_int * (int64_t)sizeof(double);
+    DevBuf u, ep, eo, s, ds, ip, kd, f, cnt;
+    FEP_TRY(u.from(u_h, c->n_dof * (int64_t)sizeof(double)));
+    if (ep_prev_h) FEP_TRY(ep.from(ep_prev_h, 4 * nb));
+    if (e_out_h) FEP_TRY(eo.alloc(3 * nb));
+    if (s_h) FEP_TRY(s.alloc(4 * nb));
+    if (ds_h) FEP_TRY(ds.alloc(9 * nb));
+    if (ind_p_h) FEP_TRY(ip.alloc(c->n_int));
+    if (k_data_h) FEP_TRY(kd.alloc(c->nnz * (int64_t)sizeof(double)));
+    if (f_out_h) FEP_TRY(f.alloc(c->n_dof * (int64_t)sizeof(double)));
+    FEP_TRY(cnt.alloc(2 * sizeof(int64_t)));
+    FEP_TRY(fep_step_dev(c, nullptr, u.as<double>(), e0_h, ep.as<double>(), accept, eo.as<double>(), s.as<double>(),
+                         ds.as<double>(), ip.as<uint8_t>(), kd.as<double>(), f.as<double>(), cnt.as<int64_t>()));
+    HIP_TRY(hipDeviceSynchronize());
+    if (e_out_h) FEP_TRY(eo.to(e_out_h, 3 * nb));
+    if (s_h) FEP_TRY(s.to(s_h, 4 * nb));
+    if (ds_h) FEP_TRY(ds.to(ds_h, 9 * nb));
+    if (ind_p_h) FEP_TRY(ip.to(ind_p_h, c->n_int));
+    if (k_data_h) FEP_TRY(kd.to(k_data_h, c->nnz * (int64_t)sizeof(double)));
+    if (f_out_h) FEP_TRY(f.to(f_out_h, c->n_dof * (int64_t)sizeof(double)));
+    if (counts_h) FEP_TRY(cnt.to(counts_h, 2 * sizeof(int64_t)));
+    if (accept && ep_prev_h) FEP_TRY(ep.to(ep_prev_h, 4 * nb));
+    return FEP_OK;
+}
+
+extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s_h, double* k_data_h, double* f_out_h) {
+    if (!c) return FEP_EINVAL;
+    if ((k_data_h && !ds_h) || (f_out_h && !s_h)) return FEP_EINVAL;
+    FEP_TRY(set_device(c->device));
+    const int64_t nb = c->n_int * (int64_t)sizeof(double);
+    DevBuf ds, s, kd, f;
+    if (ds_h) FEP_TRY(ds.from(ds_h, 9 * nb));
+    if (s_h) FEP_TRY(s.from(s_h, 3 * nb));
+    if (k_data_h) FEP_TRY(kd.alloc(c->nnz * (int64_t)sizeof(double)));
+    if (f_out_h) FEP_TRY(f.alloc(c->n_dof * (int64_t)sizeof(double)));
+    FEP_TRY(fep_assemble_dev(c, nullptr, ds.as<double>(), s.as<double>(), kd.as<double>(), f.as<double>()));
+    HIP_TRY(hipDeviceSynchronize());
+    if (k_data_h) FEP_TRY(kd.to(k_data_h, c->nnz * (int64_t)sizeof(double)));
+    if (f_out_h) FEP_TRY(f.to(f_out_h, c->n_dof * (int64_t)sizeof(double)));
+    return FEP_OK;
+}
+
+extern "C" const char* fep_step_kernel_names(const fep_ctx*) {
+    return "element_kernel\0csr_reduce_kernel\0force_reduce_kernel\0";
+}
+
+extern "C" int fep_step_kernel_time(fep_ctx* c, void* stream, int reps, const double* u_d, const double* e0_h,
+                                    double* ep_prev_d, double* s_d, double* ds_d, uint8_t* ind_p_d, float* ms_out) {
+    if (!c || !u_d || !ms_out || reps <= 0) return FEP_EINVAL;
+    if (!c->have_materials) return FEP_ESTATE;
+    FEP_TRY(set_device(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    const E0 e0 = make_e0(e0_h);
+    int r = FEP_OK;
+    (void)hipEventRecord(ev0, st);
+    for (int i = 0; i < reps && r == FEP_OK; ++i) {
+#define CALL(NP, NQ) \
+    r = launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, 0, nullptr, s_d, ds_d, ind_p_d, nullptr, c->Kc, c->fe)
+        switch (c->elem_type) {
+            case FEP_P1: CALL(3, 1); break;
+            case FEP_P2: CALL(6, 7); break;
+            case FEP_Q1: CALL(4, 4); break;
+            case FEP_Q2: CALL(8, 9); break;
+            case FEP_P4: CALL(15, 12); break;
+        }
+#undef CALL
+    }
+    (void)hipEventRecord(ev1, st);
+    hipError_t e = hipEventSynchronize(ev1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (r != FEP_OK) return r;
+    if (e != hipSuccess) { g_last_hip = (int)e; return FEP_EHIP; }
+    *ms_out = ms / (float)reps;
+    return FEP_OK;
+}

@@ -1,0 +1,355 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the Drucker-Prager return map and the element
+// tangent / internal-force assembly.  fp64 throughout.  All per-point arrays are SoA
+// ("rows x n_int", component-major) so that consecutive lanes read consecutive doubles.
+//
+// Reference lines restated here (DP = Plasticity2D_DP/pythonFEM.py):
+//   geometry            DP:506-546, 585
+//   strain              DP:1043
+//   return map          DP:646-757 (+ TSX:1052 initial strain)
+//   element tangent     DP:1047-1050  (K_e = sum_q w_q B_q^T DS_q B_q)
+//   internal force      DP:1058       (f_e = sum_q w_q B_q^T S_q[0:3])
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fep {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------
+// Per-point Drucker-Prager return map (DP:663-755).
+//   e[3]  strain (11,22,gamma12);  z[4] initial strain (TSX e0, zeros for DP);  p[4] previous
+//   plastic strain.  Outputs: s[4] stress, d[6] symmetric tangent (00,01,02,11,12,22),
+//   p[4] updated in place when `accept`.  Returns 0 elastic, 1 smooth, 2 apex.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int dp_return_map(const double e[3], const double z[4], double p[4],
+                                             double G, double K, double eta, double c, bool accept,
+                                             double s[4], double d[6]) {
+    const double I3 = 1.0 / 3.0;
+    const double DD = 1.0 - 1.0 / 3.0;          // diagonal of dev (DP:653)
+    const double RS2 = 1.4142135623730951;      // np.sqrt(2)
+    const double Et0 = (e[0] + z[0]) - p[0];    // DP:663-668 (C3: E4 aliases E_tr)
+    const double Et1 = (e[1] + z[1]) - p[1];
+    const double Et2 = (e[2] + z[2]) - p[2];
+    const double Et3 = (0.0 + z[3]) - p[3];
+    const double tr = Et0 + Et1 + Et3;          // vol @ E_tr
+    const double dv0 = DD * Et0 - I3 * Et1 - I3 * Et3;   // dev @ E_tr, DP:673
+    const double dv1 = -I3 * Et0 + DD * Et1 - I3 * Et3;
+    const double dv2 = 0.5 * Et2;
+    const double dv3 = -I3 * Et0 - I3 * Et1 + DD * Et3;
+    const double G2 = 2.0 * G;
+    const double Ktr = K * tr;                  // p_tr, DP:682
+    double s0 = G2 * dv0 + Ktr, s1 = G2 * dv1 + Ktr, s2 = G2 * dv2, s3 = G2 * dv3 + Ktr;   // DP:670
+    const double n2 = Et0 * dv0 + Et1 * dv1 + Et2 * dv2 + Et3 * dv3;
+    const double nE = sqrt(n2 > 0.0 ? n2 : 0.0);          // DP:676 (C5)
+    const double rho = 2.0 * (G * nE);                    // DP:679
+    const double da = K * (eta * eta);                    // DP:687
+    const double dS = G + da;                             // DP:688
+    const double c1 = rho / RS2 + eta * Ktr - c;          // DP:689
+    const double c2 = eta * Ktr - da * rho / (G * RS2) - c;   // DP:690
+    // elastic tangent 2*Dev*G + Vol*K, DP:703
+    double d00 = 2.0 * DD * G + K, d01 = 2.0 * (-I3) * G + K, d02 = 0.0;
+    double d11 = d00, d12 = 0.0, d22 = 2.0 * 0.5 * G;
+    int branch = 0;
+    if (c1 > 0.0) {                                       // DP:693
+        if (c2 <= 0.0) {                                  // smooth portion, DP:696
+            branch = 1;
+            const double lam = c1 / dS;                   // DP:710
+            const double N0 = dv0 / nE, N1 = dv1 / nE, N2 = dv2 / nE, N3 = dv3 / nE;   // DP:718
+            const double Ke = K * eta;
+            const double g = RS2 * G;
+            const double M0 = g * N0 + Ke, M1 = g * N1 + Ke, M2 = g * N2, M3 = g * N3 + Ke;  // DP:719
+            s0 -= lam * M0; s1 -= lam * M1; s2 -= lam * M2; s3 -= lam * M3;   // DP:720
+            const double cf = 2.0 * RS2 * (G * G) * lam / rho;               // DP:727
+            d00 = d00 - cf * (DD - N0 * N0) - M0 * M0 / dS;
+            d01 = d01 - cf * (-I3 - N0 * N1) - M0 * M1 / dS;
+            d02 = d02 - cf * (0.0 - N0 * N2) - M0 * M2 / dS;
+            d11 = d11 - cf * (DD - N1 * N1) - M1 * M1 / dS;
+            d12 = d12 - cf * (0.0 - N1 * N2) - M1 * M2 / dS;
+            d22 = d22 - cf * (0.5 - N2 * N2) - M2 * M2 / dS;
+            if (accept) {                                 // DP:752
+                const double e3 = eta / 3.0;
+                p[0] += lam * (N0 / RS2 + e3);
+                p[1] += lam * (N1 / RS2 + e3);
+                p[2] += 2.0 * lam * (N2 / RS2);
+                p[3] += lam * (N3 / RS2 + e3);
+            }
+        } else {                                          // apex, DP:699
+            branch = 2;
+            const double ce = c / eta;                    // DP:721
+            s0 = ce; s1 = ce; s2 = 0.0; s3 = ce;
+            d00 = d01 = d02 = d11 = d12 = d22 = 0.0;      // DP:728
+            if (accept) {                                 // DP:755 (uses E - ep_prev: C3)
+                const double sh = c / (3.0 * K * eta);
+                p[0] = Et0 - sh; p[1] = Et1 - sh; p[2] = Et2; p[3] = Et3 - sh;
+            }
+        }
+    }
+    s[0] = s0; s[1] = s1; s[2] = s2; s[3] = s3;
+    d[0] = d00; d[1] = d01; d[2] = d02; d[3] = d11; d[4] = d12; d[5] = d22;
+    return branch;
+}
+
+// one atomic per wave for the smooth / apex counters (integer => deterministic)
+__device__ __forceinline__ void count_branches(int branch, unsigned long long* counts) {
+    if (counts == nullptr) return;
+    const unsigned long long ms = __ballot(branch == 1);
+    const unsigned long long ma = __ballot(branch == 2);
+    if ((threadIdx.x & 63) == 0) {
+        if (ms) atomicAdd(&counts[0], (unsigned long long)__popcll(ms));
+        if (ma) atomicAdd(&counts[1], (unsigned long long)__popcll(ma));
+    }
+}
+
+__device__ __forceinline__ void store_point(int64_t k, int64_t n, const double s[4], const double d[6], int branch,
+                                            double* __restrict__ S, double* __restrict__ DS,
+                                            uint8_t* __restrict__ indp) {
+    if (S) { S[k] = s[0]; S[n + k] = s[1]; S[2 * n + k] = s[2]; S[3 * n + k] = s[3]; }
+    if (DS) {   // row-major 3x3, m = 3i+j (DP:703)
+        DS[k] = d[0];         DS[n + k] = d[1];     DS[2 * n + k] = d[2];
+        DS[3 * n + k] = d[1]; DS[4 * n + k] = d[3]; DS[5 * n + k] = d[4];
+        DS[6 * n + k] = d[2]; DS[7 * n + k] = d[4]; DS[8 * n + k] = d[5];
+    }
+    if (indp) indp[k] = branch != 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Mesh-free pointwise return map: construct_constitutive_problem (DP:604-757 / TSX:990-1157).
+// ---------------------------------------------------------------------------------------
+struct E0 { double v[4]; };
+
+__global__ void __launch_bounds__(kBlock)
+return_map_kernel(int64_t n, const double* __restrict__ e, int64_t eps, int64_t ecs, E0 e0,
+                  double* __restrict__ ep, const double* __restrict__ shear, const double* __restrict__ bulk,
+                  const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+                  double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
+                  unsigned long long* counts) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int branch = 0;
+    if (k < n) {
+        double ev[3] = {e[k * eps], e[k * eps + ecs], e[k * eps + 2 * ecs]};
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ep) { p[0] = ep[k]; p[1] = ep[n + k]; p[2] = ep[2 * n + k]; p[3] = ep[3 * n + k]; }
+        double s[4], d[6];
+        branch = dp_return_map(ev, e0.v, p, shear[k], bulk[k], eta[k], cc[k], accept != 0, s, d);
+        store_point(k, n, s, d, branch, S, DS, indp);
+        if (accept && ep && branch) { ep[k] = p[0]; ep[n + k] = p[1]; ep[2 * n + k] = p[2]; ep[3 * n + k] = p[3]; }
+    }
+    count_branches(branch, counts);
+}
+
+// ---------------------------------------------------------------------------------------
+// Geometry (setup, once): Jacobian, dphi_1, dphi_2, weight.  DP:530-546, 585.
+// Operation order and rounding follow the reference's NumPy expressions exactly
+// (no FMA contraction), so dphi / weight are bit-identical to the reference's arrays.
+// ---------------------------------------------------------------------------------------
+template <int NP, int NQ>
+__global__ void __launch_bounds__(kBlock)
+geometry_kernel(int64_t n_e, int64_t n_n, const int32_t* __restrict__ elem, const double* __restrict__ coords,
+                const double* __restrict__ dh1, const double* __restrict__ dh2, const double* __restrict__ wf,
+                double* __restrict__ dphi1, double* __restrict__ dphi2, double* __restrict__ weight,
+                double* __restrict__ det_out) {
+#pragma clang fp contract(off)
+    __shared__ double t1[NP * NQ], t2[NP * NQ], tw[NQ];
+    for (int i = threadIdx.x; i < NP * NQ; i += kBlock) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+    for (int i = threadIdx.x; i < NQ; i += kBlock) tw[i] = wf[i];
+    __syncthreads();
+    const int64_t n_int = n_e * NQ;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_int) return;
+    const int64_t e = k / NQ;
+    const int q = (int)(k - e * NQ);
+    double j11 = 0.0, j12 = 0.0, j21 = 0.0, j22 = 0.0;
+    for (int a = 0; a < NP; ++a) {                       // builtin sum over rows, DP:530-533
+        const int32_t nd = elem[(int64_t)a * n_e + e];
+        const double x = coords[nd], y = coords[n_n + nd];
+        const double h1 = t1[a * NQ + q], h2 = t2[a * NQ + q];
+        j11 = j11 + x * h1; j12 = j12 + y * h1; j21 = j21 + x * h2; j22 = j22 + y * h2;
+    }
+    const double det = j11 * j22 - j12 * j21;            // DP:536
+    const double i11 = j22 / det, i12 = -j12 / det, i21 = -j21 / det, i22 = j11 / det;   // DP:539-542
+    for (int a = 0; a < NP; ++a) {
+        const double h1 = t1[a * NQ + q], h2 = t2[a * NQ + q];
+        dphi1[(int64_t)a * n_int + k] = i11 * h1 + i12 * h2;   // DP:545
+        dphi2[(int64_t)a * n_int + k] = i21 * h1 + i22 * h2;   // DP:546
+    }
+    weight[k] = fabs(det) * tw[q];                       // DP:585
+    if (det_out) det_out[k] = det;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused element kernel.  One workgroup = EB consecutive elements = EB*NQ consecutive points.
+//
+//  phase 1 (one lane per integration point): strain from U (a1), return map (a2), results to
+//          HBM (coalesced over k) and w*DS, w*S, dphi staged in LDS;
+//  phase 2 (one lane per (element, local node a)): rows 2a, 2a+1 of K_e = sum_q B^T (w DS) B (a3, a4)
+//          and of f_e = sum_q B^T (w S) (a5), written as 2x2 node-pair blocks
+//          Kc[((a*NP+b)*n_e + e)*4 + 2i+j] and pairs fe[(a*n_e+e)*2 + i].
+//
+//  FROM_U = true : inputs U (+ ep, materials);  FROM_U = false : inputs DS, S (assembly only).
+// ---------------------------------------------------------------------------------------
+template <int NP, int NQ> struct ElemCfg {
+    static constexpr int maxpq = NP > NQ ? NP : NQ;
+    static constexpr int EB = (kBlock / maxpq) >= 64 ? 64 : ((kBlock / maxpq) >= 32 ? 32 : (kBlock / maxpq));
+    static constexpr int NQS = NQ | 1;                  // odd LDS stride: conflict-free ds_read_b64 over elements
+    static constexpr int NPTS = EB * NQS;
+};
+
+template <int NP, int NQ, bool FROM_U>
+__global__ void __launch_bounds__(kBlock)
+element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
+               const double* __restrict__ dphi1, const double* __restrict__ dphi2, const double* __restrict__ weight,
+               // FROM_U inputs
+               const double* __restrict__ U, E0 e0, double* __restrict__ ep,
+               const double* __restrict__ shear, const double* __restrict__ bulk,
+               const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+               // outputs of phase 1 (FROM_U) or inputs (!FROM_U)
+               double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
+               unsigned long long* counts,
+               // outputs of phase 2
+               double* __restrict__ Kc, double* __restrict__ fe) {
+    using C = ElemCfg<NP, NQ>;
+    constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
+    __shared__ double d1s[NP][NPTS], d2s[NP][NPTS];
+    __shared__ double Ds[6][NPTS], Ss[3][NPTS];
+    __shared__ int32_t nds[NP][EB];
+
+    const int t = threadIdx.x;
+    const int64_t e0blk = (int64_t)blockIdx.x * EB;
+    const int64_t n_int = n_e * NQ;
+    const int nel = (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
+
+    if (FROM_U) {
+        for (int i = t; i < NP * EB; i += kBlock) {
+            const int a = i / EB, el = i - a * EB;
+            nds[a][el] = el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 1 --------------------------------------------------------------------
+    int branch = 0;
+    for (int pt = t; pt < EB * NQ; pt += kBlock) {
+        const int el = pt / NQ, q = pt - el * NQ;
+        if (el >= nel) continue;
+        const int64_t k = e0blk * NQ + pt;
+        const int li = el * NQS + q;
+        const double w = weight[k];
+        double s[4], d[6];
+        if (FROM_U) {
+            double ev[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+                const double g1 = dphi1[(int64_t)a * n_int + k], g2 = dphi2[(int64_t)a * n_int + k];
+                d1s[a][li] = g1; d2s[a][li] = g2;
+                const int32_t nd = nds[a][el];
+                const double ux = U[2 * (int64_t)nd], uy = U[2 * (int64_t)nd + 1];
+                ev[0] += g1 * ux; ev[1] += g2 * uy; ev[2] += g2 * ux + g1 * uy;   // DP:1043
+            }
+            double p[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
+            branch = dp_return_map(ev, e0.v, p, shear[k], bulk[k], eta[k], cc[k], accept != 0, s, d);
+            store_point(k, n_int, s, d, branch, S, DS, indp);
+            if (Eout) { Eout[k] = ev[0]; Eout[n_int + k] = ev[1]; Eout[2 * n_int + k] = ev[2]; }
+            if (accept && ep && branch) {
+                ep[k] = p[0]; ep[n_int + k] = p[1]; ep[2 * n_int + k] = p[2]; ep[3 * n_int + k] = p[3];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+                d1s[a][li] = dphi1[(int64_t)a * n_int + k];
+                d2s[a][li] = dphi2[(int64_t)a * n_int + k];
+            }
+            if (DS) {
+                d[0] = DS[k]; d[1] = DS[n_int + k]; d[2] = DS[2 * n_int + k];
+                d[3] = DS[4 * n_int + k]; d[4] = DS[5 * n_int + k]; d[5] = DS[8 * n_int + k];
+            } else { d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.0; }
+            if (S) { s[0] = S[k]; s[1] = S[n_int + k]; s[2] = S[2 * n_int + k]; } else { s[0] = s[1] = s[2] = 0.0; }
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) Ds[m][li] = w * d[m];                        // vD = w*ds, DP:1047
+        Ss[0][li] = w * s[0]; Ss[1][li] = w * s[1]; Ss[2][li] = w * s[2];        // DP:1058
+    }
+    if (FROM_U) count_branches(branch, counts);
+    __syncthreads();
+
+    // ---- phase 2 --------------------------------------------------------------------
+    for (int i = t; i < NP * EB; i += kBlock) {
+        const int a = i / EB, el = i - a * EB;
+        if (el >= nel) continue;
+        const int64_t e = e0blk + el;
+        double k0[2 * NP], k1[2 * NP];
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) { k0[j] = 0.0; k1[j] = 0.0; }
+        double f0 = 0.0, f1 = 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            const int li = el * NQS + q;
+            const double D00 = Ds[0][li], D01 = Ds[1][li], D02 = Ds[2][li];
+            const double D11 = Ds[3][li], D12 = Ds[4][li], D22 = Ds[5][li];
+            const double a1 = d1s[a][li], a2 = d2s[a][li];
+            f0 += a1 * Ss[0][li] + a2 * Ss[2][li];
+            f1 += a2 * Ss[1][li] + a1 * Ss[2][li];
+            // rows of B_a^T D:  r0 = (a1,0,a2) D,  r1 = (0,a2,a1) D
+            const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
+            const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
+                const double b1 = d1s[b][li], b2 = d2s[b][li];
+                k0[2 * b]     += r00 * b1 + r02 * b2;
+                k0[2 * b + 1] += r01 * b2 + r02 * b1;
+                k1[2 * b]     += r10 * b1 + r12 * b2;
+                k1[2 * b + 1] += r11 * b2 + r12 * b1;
+            }
+        }
+        if (Kc) {
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
+                double2* dst = reinterpret_cast<double2*>(Kc + ((int64_t)(a * NP + b) * n_e + e) * 4);
+                dst[0] = make_double2(k0[2 * b], k0[2 * b + 1]);
+                dst[1] = make_double2(k1[2 * b], k1[2 * b + 1]);
+            }
+        }
+        if (fe) *reinterpret_cast<double2*>(fe + ((int64_t)a * n_e + e) * 2) = make_double2(f0, f1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Numeric COO -> CSR phase: one lane per node-pair block (row node n, neighbour slot s).
+// Deterministic: contributions are summed in the fixed order of `perm` (no atomics).
+//   segptr[n_blk+1], perm[...] = (a*NP+b)*n_e + e,  meta[blk] = (deg(n) << 16) | s
+//   CSR data: row 2n+i starts at 4*nptr[n] + i*2*deg, entry (slot s, comp j) at + 2s + j.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+csr_reduce_kernel(int64_t n_blk, const int32_t* __restrict__ segptr, const int32_t* __restrict__ perm,
+                  const uint32_t* __restrict__ meta, const double* __restrict__ Kc, double* __restrict__ data) {
+    const int64_t sb = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (sb >= n_blk) return;
+    const int32_t beg = segptr[sb], end = segptr[sb + 1];
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    for (int32_t t = beg; t < end; ++t) {
+        const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)perm[t] * 4);
+        const double2 r0 = src[0], r1 = src[1];
+        a00 += r0.x; a01 += r0.y; a10 += r1.x; a11 += r1.y;
+    }
+    const uint32_t m = meta[sb];
+    const int64_t s = m & 0xffffu, deg = m >> 16;
+    const int64_t pos0 = 4 * sb - 2 * s;
+    *reinterpret_cast<double2*>(data + pos0) = make_double2(a00, a01);
+    *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(a10, a11);
+}
+
+// Internal force: one lane per node; sums the element pairs fe[(a*n_e+e)*2 + i] in incidence order.
+__global__ void __launch_bounds__(kBlock)
+force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t* __restrict__ ilist,
+                    const double* __restrict__ fe, double* __restrict__ F) {
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_n) return;
+    double f0 = 0.0, f1 = 0.0;
+    for (int32_t t = iptr[n]; t < iptr[n + 1]; ++t) {
+        const double2 v = *reinterpret_cast<const double2*>(fe + (int64_t)ilist[t] * 2);
+        f0 += v.x; f1 += v.y;
+    }
+    *reinterpret_cast<double2*>(F + 2 * n) = make_double2(f0, f1);
+}
+
+}  // namespace fep

@@ -1,0 +1,177 @@
+/*
+ * fep.h — C ABI of libfep_hip.so: the MI355X (gfx950) implementation of the
+ * reference's per-integration-point Drucker–Prager return map and per-element
+ * tangent-stiffness / internal-force assembly.
+ *
+ * The reference (MartinBeseda/FEM-ElastoPlasticity) is pure Python and has no FFI;
+ * its "operator interface" for this path is a set of module-level functions.
+ * Each entry point below names the reference lines it replaces
+ * (DP = Plasticity2D_DP/pythonFEM.py, TSX = tsx-tunnel/pythonFEM.py,
+ *  EL = Elasticity2D/pythonFEM.py).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - every function returns 0 (FEP_OK) or a negative FEP_E* code; nothing throws or aborts;
+ *   - `double` is IEEE fp64; node/element indices are int32_t, 0-based; sizes are int64_t;
+ *   - integration point id  k = e*n_q + q  (q fastest)                       DP:510-511,526-527
+ *   - DOF id = 2*node + comp (U, F are the column-major flattening of (2,n_n)) DP:560-565, DP:1043
+ *   - strain/stress 3-vectors [11,22,12(engineering)], 4-vectors [11,22,12,33] DP:651
+ *   - per-point arrays are "rows x n_int", C-contiguous (component-major, SoA),
+ *     exactly the reference's (4,n_int)/(9,n_int) NumPy arrays;
+ *   - `ds` holds the 3x3 consistent tangent row-major, m = 3*i + j            DP:703
+ *   - pointers named *_h are host memory, *_d are device (HBM) memory of the
+ *     context's GPU; the caller owns every pointer for the duration of the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); *_dev
+ *     calls only enqueue work and return, *_host calls are synchronous;
+ *   - calls on one context are not re-entrant; one context per (host thread, GPU).
+ */
+#ifndef FEP_H
+#define FEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEP_OK            0
+#define FEP_EINVAL       -1   /* bad argument (NULL pointer, negative size, unknown element type) */
+#define FEP_ENODEV       -2   /* no usable HIP device / hipSetDevice failed */
+#define FEP_ENOMEM       -3   /* host or device allocation failed */
+#define FEP_EHIP         -4   /* a HIP runtime call or kernel launch failed (see fep_last_hip_error) */
+#define FEP_ERANGE       -5   /* an index is out of range (element -> node id, 32-bit offset overflow) */
+#define FEP_ESTATE       -6   /* call order violated (e.g. materials not set) */
+
+/* LagrangeElementType values of the reference (DP:55-60, TSX:57-63) */
+#define FEP_P1 1
+#define FEP_P2 2
+#define FEP_Q1 3
+#define FEP_Q2 4
+#define FEP_P4 5
+
+typedef struct fep_ctx fep_ctx;
+
+/* ---- library ------------------------------------------------------------------------ */
+int         fep_version(void);                 /* ABI version, currently 1 */
+const char* fep_strerror(int code);
+int         fep_last_hip_error(void);          /* raw hipError_t of the last FEP_EHIP on this thread */
+int         fep_device_count(int* n_out);
+/* (n_p, n_q) of an element type; FEP_EINVAL if unknown.  Tables: DP:364-488, TSX:67-274. */
+int         fep_element_shape(int elem_type, int* n_p, int* n_q);
+
+/* ---- device memory helpers (for callers that do not bring their own allocator) ------- */
+int fep_malloc(int device_id, void** ptr_d, int64_t bytes);
+int fep_free(int device_id, void* ptr_d);
+int fep_memcpy_h2d(int device_id, void* dst_d, const void* src_h, int64_t bytes);
+int fep_memcpy_d2h(int device_id, void* dst_h, const void* src_d, int64_t bytes);
+int fep_sync(int device_id, void* stream);
+
+/* ---- a2: return map, mesh-free (pointwise) --------------------------------------------
+ * Replaces construct_constitutive_problem, DP:604-757 (e0_h == NULL) and TSX:990-1157
+ * (e0_h = the broadcast (4,1) initial strain).
+ *
+ *   e          strain, component i of point k at e[k*e_pt_stride + i*e_comp_stride]
+ *              ((3,n_int) C-order: (1, n_int); the driver's F-ordered array DP:1043: (3, 1)); never modified
+ *   ep_prev    (4,n_int) or NULL (= zeros, DP:667).  If `accept` != 0 it is UPDATED IN PLACE
+ *              (the reference returns the mutated `ep_prev` as 'ep', DP:751-755)
+ *   shear,bulk,eta,c   (n_int) each
+ *   s          out (4,n_int)   ds  out (9,n_int)   ind_p  out (n_int) 0/1 bytes
+ *   counts     out [2] = {n_smooth, n_apex} (the numbers the reference logs at DP:730); may be NULL
+ */
+int fep_return_map_host(int device_id, int64_t n_int,
+                        const double* e_h, int64_t e_pt_stride, int64_t e_comp_stride,
+                        const double* e0_h, double* ep_prev_h,
+                        const double* shear_h, const double* bulk_h, const double* eta_h, const double* c_h,
+                        int accept,
+                        double* s_h, double* ds_h, uint8_t* ind_p_h, int64_t* counts_h);
+
+/* Same on device-resident arrays.  `counts_d` (2 x int64, device) is zeroed and filled by the call. */
+int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
+                       const double* e_d, int64_t e_pt_stride, int64_t e_comp_stride,
+                       const double* e0_h, double* ep_prev_d,
+                       const double* shear_d, const double* bulk_d, const double* eta_d, const double* c_d,
+                       int accept,
+                       double* s_d, double* ds_d, uint8_t* ind_p_d, int64_t* counts_d);
+
+/* ---- a6/a7: mesh context (static operands of the hot path) ----------------------------
+ * Replaces the geometry / index part of get_elastic_stiffness_matrix
+ * (DP:491-601, TSX:432-542, EL:368-477): Jacobians, dphi_1/dphi_2, weight = |det|*wf,
+ * and the symbolic pattern of K = B^T D B.
+ *
+ *   elements   (n_p, n_e) C-order, 0-based node ids (the reference's `elements`; EL passes 1-based
+ *              and shifts in place, EL:389 — shift before calling)
+ *   coords     (2, n_n) C-order
+ *   dhatp1/2   (n_p, n_q) C-order reference-element derivative tables, wf (n_q) weight factors
+ */
+int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type,
+                   int64_t n_e, int64_t n_n,
+                   const int32_t* elements_h, const double* coords_h,
+                   const double* dhatp1_h, const double* dhatp2_h, const double* wf_h);
+int fep_ctx_destroy(fep_ctx* ctx);
+
+/* sizes[0..7] = n_e, n_n, n_p, n_q, n_int, n_dof (=2*n_n), nnz (CSR entries of K), n_blk (node-pair blocks) */
+int fep_ctx_sizes(const fep_ctx* ctx, int64_t sizes[8]);
+
+/* dphi1, dphi2: (n_p, n_int); weight: (n_int); det: (n_int) or NULL.       DP:530-546, 585 */
+int fep_ctx_geometry_host(fep_ctx* ctx, double* dphi1_h, double* dphi2_h, double* weight_h, double* det_h);
+
+/* Symbolic CSR pattern of K (rows = DOFs, sorted columns, every structural entry of B^T D B kept,
+ * also those that are numerically zero — the reference's SciPy product drops them). */
+int fep_ctx_pattern_host(const fep_ctx* ctx, int32_t* indptr_h /* n_dof+1 */, int32_t* indices_h /* nnz */);
+
+/* Per-point material parameters (n_int each): shear, bulk (DP:972-973), eta, c (DP:983-984). */
+int fep_ctx_set_materials_host(fep_ctx* ctx, const double* shear_h, const double* bulk_h,
+                               const double* eta_h, const double* c_h);
+/* Device pointers of the context's static per-point arrays (for the mesh-free entry points):
+ * which = 0 shear, 1 bulk, 2 eta, 3 c, 4 weight, 5 dphi1, 6 dphi2. */
+int fep_ctx_device_ptr(const fep_ctx* ctx, int which, void** ptr_d);
+
+/* ---- a1..a5 fused: one pass of the hot path ------------------------------------------
+ * Replaces, for one Newton iterate (DP:1043-1058 / TSX:1771-1778):
+ *     E = B*U                                   (a1)
+ *     construct_constitutive_problem(E, ...)     (a2)
+ *     vD = w*ds ; D_p ; K_tangent = K_elast + B^T (D_p - D_elast) B   (a3, a4)
+ *     F = B^T (w * s[0:3])                       (a5)
+ * K_tangent is produced as the `data` array of the context's CSR pattern, computed as
+ * B^T D_p B directly (equal to the reference's expression up to fp64 rounding).
+ *
+ *   U          (n_dof) displacement, DOF order
+ *   e0_h       4 host doubles (TSX initial strain zeta*e_init, TSX:1765) or NULL
+ *   ep_prev    (4,n_int) or NULL; updated in place when accept != 0
+ *   e_out      (3,n_int) C-order strain or NULL (not needed by the path itself)
+ *   s, ds, ind_p   as in fep_return_map_*; any of them may be NULL when not wanted
+ *   k_data     out (nnz)     f_out  out (n_dof)
+ *   counts     out [2] {n_smooth, n_apex} or NULL
+ */
+int fep_step_dev(fep_ctx* ctx, void* stream, const double* u_d, const double* e0_h,
+                 double* ep_prev_d, int accept,
+                 double* e_out_d, double* s_d, double* ds_d, uint8_t* ind_p_d,
+                 double* k_data_d, double* f_out_d, int64_t* counts_d);
+int fep_step_host(fep_ctx* ctx, const double* u_h, const double* e0_h,
+                  double* ep_prev_h, int accept,
+                  double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
+                  double* k_data_h, double* f_out_h, int64_t* counts_h);
+
+/* ---- a3..a5 only: assembly from given ds / s ------------------------------------------
+ * Replaces DP:1047-1050 + DP:1058 when the caller already holds `ds` (9,n_int) and `s` (>=3 rows
+ * used, (4,n_int) layout).  Either output may be NULL.  With ds = the elastic tensor this is the
+ * K_elast = B^T D B of DP:595. */
+int fep_assemble_dev(fep_ctx* ctx, void* stream, const double* ds_d, const double* s_d,
+                     double* k_data_d, double* f_out_d);
+int fep_assemble_host(fep_ctx* ctx, const double* ds_h, const double* s_h,
+                      double* k_data_h, double* f_out_h);
+
+/* Kernel-only timing hook used by bench.py: average milliseconds per launch of the dominant kernel
+ * of the last fep_step_dev call sequence is measured by the caller with HIP events on `stream`;
+ * this returns the names of the kernels a step launches (NUL-separated list, double-NUL terminated). */
+const char* fep_step_kernel_names(const fep_ctx* ctx);
+
+/* Timed replay for bench.py: enqueue `reps` launches of ONLY the dominant (fused element) kernel of
+ * a step between two HIP events on `stream` and return the average ms per launch in *ms_out.
+ * Inputs/outputs as fep_step_dev (same buffers are rewritten each launch). */
+int fep_step_kernel_time(fep_ctx* ctx, void* stream, int reps, const double* u_d, const double* e0_h,
+                         double* ep_prev_d, double* s_d, double* ds_d, uint8_t* ind_p_d, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEP_H */

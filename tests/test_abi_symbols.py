@@ -1,0 +1,68 @@
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/fep.h declares.
+No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def built(fep):
+    fep.build()
+    return fep
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'fep.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    names = re.findall(r'\b(fep_[a-z0-9_]+)\s*\(', txt)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported(built):
+    names = _declared()
+    assert len(names) >= 24
+    l = ctypes.CDLL(built.lib_path())
+    missing = [n for n in names if not hasattr(l, n)]
+    assert not missing, missing
+    # and the Python binding table covers exactly the header
+    from importlib import import_module
+    proto = import_module('fem-elastoplasticity_amd._lib').PROTOTYPES
+    assert sorted(proto) == names
+
+
+def test_library_metadata_calls(built):
+    l = built.lib()
+    assert l.fep_version() == 1
+    assert l.fep_strerror(0) == b'ok' and l.fep_strerror(-5) == b'index out of range'
+    for t, (p, q) in {1: (3, 1), 2: (6, 7), 3: (4, 4), 4: (8, 9), 5: (15, 12)}.items():
+        a, b = ctypes.c_int(), ctypes.c_int()
+        assert l.fep_element_shape(t, ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value, b.value) == (p, q)
+    assert l.fep_element_shape(0, None, None) == -1
+    assert l.fep_ctx_destroy(None) == 0 and l.fep_ctx_sizes(None, None) == -1
+
+
+def test_gfx950_code_object_present(built):
+    blob = open(built.lib_path(), 'rb').read()
+    assert b'gfx950' in blob and b'element_kernel' in blob
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    from importlib import import_module
+    m = import_module('fem-elastoplasticity_amd._lib')
+    monkeypatch.setattr(m, '_LIB', None)
+    monkeypatch.setattr(m, 'lib_path', lambda: '/nonexistent/libfep_hip.so')
+    with pytest.raises(ImportError, match='no CPU fallback'):
+        m.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'fem-elastoplasticity_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in txt.replace('no oracle', ''), f

@@ -1,0 +1,367 @@
+"""
+Parity of the HIP path (through the C ABI, libfep_hip.so) with
+  (i)  golden vectors recorded from the reference itself (tests/golden/*.npz), and
+  (ii) the oracle (oracle/fep_oracle.py) on seeded inputs,
+plus size-independent properties at the benchmark's full size.
+
+Tolerances (fp64): stresses / tangents / plastic strain 1e-13 relative to the array's max
+(the reference's own 4x4 BLAS product `dev @ E_tr` has an unspecified summation order, so
+bit-equality is not defined); geometry (dphi, weight) and all index arrays bit-exact;
+K, F 1e-12 (different but fixed summation order over elements).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as ssp
+
+from conftest import dp_materials, load_golden, relerr
+from oracle import fep_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ELS = ('P1', 'P2', 'Q1', 'Q2')
+NQ = {'P1': 1, 'P2': 7, 'Q1': 4, 'Q2': 9, 'P4': 12}
+TOL_PT = 1e-13
+TOL_K = 1e-12
+
+
+def tables(mod, t):
+    g = load_golden('tables')
+    k = f'{mod}_{t}_'
+    return g[k + 'dhatp1'], g[k + 'dhatp2'], g[k + 'wf']
+
+
+# ---- a2 -------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['dp_none', 'dp_ep', 'dp_ep_accept', 'tsx_ep', 'tsx_ep_accept'])
+@pytest.mark.parametrize('order', ['C', 'F'])
+def test_return_map_vs_reference_golden(fep, case, order):
+    g = load_golden('retmap')
+    tsx = case.startswith('tsx')
+    accept = case.endswith('accept')
+    ep_in = None if case == 'dp_none' else g['Ep'].copy()
+    E = np.array(g['E'], order=order)                     # the driver passes an F-ordered array (DP:1043)
+    E_before = E.copy()
+    if tsx:
+        r = fep.tsx_tunnel.construct_constitutive_problem(E, g['e0'], ep_in, g['shear'], g['bulk'], g['eta'], g['c'], accept)
+    else:
+        r = fep.plasticity2d_dp.construct_constitutive_problem(E, ep_in, g['shear'], g['bulk'], g['eta'], g['c'], accept)
+    assert np.array_equal(E, E_before)
+    assert r['s'].shape == (4, E.shape[1]) and r['ds'].shape == (9, E.shape[1]) and r['ind_p'].dtype == np.bool_
+    assert np.array_equal(r['ind_p'], g[case + '_ind_p'])
+    assert relerr(r['s'], g[case + '_s']) <= TOL_PT
+    assert relerr(r['ds'], g[case + '_ds']) <= TOL_PT
+    if accept:
+        assert relerr(r['ep'], g[case + '_ep']) <= TOL_PT
+        assert r['ep'] is ep_in                                        # C4 aliasing
+        assert relerr(ep_in, g[case + '_ep_prev_after']) <= TOL_PT
+    else:
+        assert not r['ep'].any() and r['ep'].shape == (4, E.shape[1])
+        if ep_in is not None:
+            assert np.array_equal(ep_in, g['Ep'])                      # untouched without accept
+    assert (r['lambda_final'] is None) == bool(g[case + '_lambda_is_none'])
+    # the counts the reference logs (DP:730)
+    ref = orc.return_map(g['E'], None if ep_in is None else g['Ep'].copy(), g['shear'], g['bulk'], g['eta'], g['c'],
+                         False, e0=g['e0'] if tsx else None, tsx=tsx)
+    assert (r['n_smooth'], r['n_apex']) == (ref['n_smooth'], ref['n_apex'])
+
+
+def test_return_map_all_elastic_quirks(fep):
+    g = load_golden('retmap')
+    sh, bu, eta, c = dp_materials(64)
+    r = fep.construct_constitutive_problem(g['Eel'], np.zeros((4, 64)), sh, bu, eta, c, True)
+    assert relerr(r['s'], g['dp_elastic_s']) <= TOL_PT and relerr(r['ds'], g['dp_elastic_ds']) <= TOL_PT
+    assert r['lambda_final'] is None and not r['ep'].any()
+    ep_in = g['tsx_elastic_ep_in'].copy()
+    r = fep.construct_constitutive_problem_tsx(g['Eel'], np.zeros((4, 1)), ep_in, sh, bu, eta, c, True)
+    assert relerr(r['s'], g['tsx_elastic_s']) <= TOL_PT
+    assert np.array_equal(r['ep'], g['tsx_elastic_ep']) and r['ep'] is not ep_in     # TSX:1103 early-out
+    assert np.array_equal(r['lambda_final'], g['tsx_elastic_lambda'])
+    assert np.array_equal(ep_in, g['tsx_elastic_ep_in'])
+
+
+def test_return_map_edge_sizes(fep):
+    sh, bu, eta, c = dp_materials(0)
+    r = fep.construct_constitutive_problem(np.zeros((3, 0)), None, sh, bu, eta, c)
+    assert r['s'].shape == (4, 0) and r['ds'].shape == (9, 0) and r['n_smooth'] == 0
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 64, 65, 257, 1000):          # ragged tails of the 256-lane blocks
+        sh, bu, eta, c = dp_materials(n)
+        E = rng.normal(0, 3e-4, size=(3, n))
+        ep = rng.normal(0, 1e-5, size=(4, n))
+        a = fep.construct_constitutive_problem(E, ep.copy(), sh, bu, eta, c, True)
+        b = orc.return_map(E, ep.copy(), sh, bu, eta, c, True)
+        assert np.array_equal(a['ind_p'], b['ind_p'])
+        assert relerr(a['s'], b['s']) <= TOL_PT and relerr(a['ds'], b['ds']) <= TOL_PT and relerr(a['ep'], b['ep']) <= TOL_PT
+
+
+def test_return_map_large_random_vs_oracle(fep):
+    rng = np.random.default_rng(99)
+    n = 200_000
+    sh, bu, eta, c = dp_materials(n)
+    sh *= rng.uniform(0.5, 2, n); bu *= rng.uniform(0.5, 2, n); eta *= rng.uniform(0.5, 1.5, n); c *= rng.uniform(0.5, 2, n)
+    E = rng.normal(0, 2e-4, size=(3, n))
+    E[:, : n // 50] += 4e-4                        # a band of apex points (oracle is fine up to ~20k)
+    ep = rng.normal(0, 2e-5, size=(4, n))
+    a = fep.construct_constitutive_problem(E, ep.copy(), sh, bu, eta, c, True)
+    b = orc.return_map(E, ep.copy(), sh, bu, eta, c, True)
+    assert b['n_apex'] > 1000 and b['n_smooth'] > 10000
+    assert (a['n_smooth'], a['n_apex']) == (b['n_smooth'], b['n_apex'])
+    assert np.array_equal(a['ind_p'], b['ind_p'])
+    assert relerr(a['s'], b['s']) <= TOL_PT and relerr(a['ds'], b['ds']) <= TOL_PT and relerr(a['ep'], b['ep']) <= TOL_PT
+    # properties: yield consistency after a smooth return, apex stress, symmetric tangent
+    s, ds = a['s'], a['ds']
+    i_s = np.logical_and(a['ind_p'], np.abs(ds).sum(axis=0) > 0)
+    i_a = np.logical_and(a['ind_p'], ~i_s)
+    p = (s[0] + s[1] + s[3]) / 3
+    dev = s - p * np.array([[1], [1], [0], [1]])
+    rho = np.sqrt(dev[0] ** 2 + dev[1] ** 2 + 2 * dev[2] ** 2 + dev[3] ** 2)
+    f = rho / np.sqrt(2) + eta * p - c
+    assert np.abs(f[i_s]).max() <= 1e-9 * c.max()
+    assert np.allclose(s[0][i_a], (c / eta)[i_a], rtol=1e-15) and not s[2][i_a].any()
+    assert np.array_equal(ds[1], ds[3]) and np.array_equal(ds[2], ds[6]) and np.array_equal(ds[5], ds[7])
+
+
+# ---- a6 -------------------------------------------------------------------------------
+@pytest.mark.parametrize('t', ELS)
+def test_elastic_setup_vs_reference_golden(fep, t):
+    g = load_golden('setup_dp')
+    d1, d2, wf = tables('dp', t)
+    elem = g[f'{t}_elements'].copy()
+    K, B, w, iD, jD, D = fep.get_elastic_stiffness_matrix(elem, g[f'{t}_coordinates'], g[f'{t}_shear'], g[f'{t}_bulk'],
+                                                          d1, d2, wf)
+    assert np.array_equal(elem, g[f'{t}_elements'])                   # inputs untouched (DP flavour)
+    assert w.shape == g[f'{t}_weight'].shape and np.array_equal(w, g[f'{t}_weight'])      # bit-exact geometry
+    assert np.array_equal(iD, g[f'{t}_iD']) and np.array_equal(jD, g[f'{t}_jD'])
+    for name, M in (('B', B), ('D', D)):
+        assert M.format == 'csr' and tuple(M.shape) == tuple(g[f'{t}_{name}_shape'])
+        assert np.array_equal(M.indptr, g[f'{t}_{name}_indptr'])
+        assert np.array_equal(M.indices, g[f'{t}_{name}_indices'])    # bit-exact indexing
+        assert np.array_equal(M.data, g[f'{t}_{name}_data'])          # and bit-exact values
+    assert relerr(K.toarray(), g[f'{t}_K']) <= TOL_K
+    # our pattern is a superset of the reference's value-dependent one
+    assert not np.logical_and(g[f'{t}_K'] != 0, K.toarray() == 0).any()
+    assert K.has_sorted_indices
+
+
+# ---- a1..a5 ---------------------------------------------------------------------------
+@pytest.mark.parametrize('t', ELS)
+@pytest.mark.parametrize('accept', [False, True])
+def test_hot_path_vs_reference_golden(fep, t, accept):
+    g = load_golden('hotpath_dp')
+    d1, d2, wf = tables('dp', t)
+    elem, coord = g[f'{t}_elements'], g[f'{t}_coordinates']
+    n_int = elem.shape[1] * NQ[t]
+    sh, bu, eta, c = dp_materials(n_int)
+    ctx = fep.MeshContext(elem, coord, d1, d2, wf)
+    ctx.set_materials(sh, bu, eta, c)
+    tag = f'{t}_acc{int(accept)}_'
+    ep = g[f'{t}_Ep_old'].copy()
+    r = ctx.step(g[f'{t}_U'], ep, apply_plastic_strain=accept, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    assert relerr(r['E'], g[tag + 'E']) <= 1e-14
+    assert np.array_equal(r['ind_p'], g[tag + 'ind_p'])
+    assert relerr(r['s'], g[tag + 's']) <= TOL_PT and relerr(r['ds'], g[tag + 'ds']) <= TOL_PT
+    assert relerr(r['K'].toarray(), g[tag + 'K_t']) <= TOL_K
+    assert relerr(r['F'], g[tag + 'F']) <= TOL_K
+    if accept:
+        assert relerr(ep, g[tag + 'ep']) <= TOL_PT
+    else:
+        assert np.array_equal(ep, g[f'{t}_Ep_old'])
+    # unfused route (drop-in for the inline DP:1047-1058): same K, F from the returned ds, s
+    K2, F2 = fep.assemble_tangent(ctx, r['ds'], r['s'])
+    assert np.array_equal(K2.data, r['K'].data) and np.array_equal(F2, r['F'])
+    # run-to-run bitwise reproducible (no atomics in the value path)
+    r2 = ctx.step(g[f'{t}_U'], g[f'{t}_Ep_old'].copy(), apply_plastic_strain=accept, want=('K', 'F', 's'))
+    assert np.array_equal(r2['K'].data, r['K'].data) and np.array_equal(r2['F'], r['F'])
+    ctx.close()
+
+
+# ---- config 3: tsx-tunnel CSV dumps ------------------------------------------------------
+def _tsx_ctx(fep, t, coord, elem):
+    d1, d2, wf = tables('tsx', t) if t != 'P1' else tables('dp', 'P1')
+    n_int = elem.shape[1] * NQ[t]
+    G = 60000 / (2 * (1 + 0.2)) * np.ones(n_int)
+    Kb = 60000 / (3 * (1 - 2 * 0.2)) * np.ones(n_int)
+    K, B, w, iD, jD, D = fep.tsx_tunnel.get_elastic_stiffness_matrix(elem, coord, G, Kb, d1, d2, wf)
+    Q = np.ones(coord.shape, dtype=bool)
+    Q[0, np.abs(coord[0]) > 49.99] = 0
+    Q[1, np.abs(coord[1]) > 49.99] = 0
+    return K, B, w, Q
+
+
+def test_tsx_p1_tangent_vs_k_tangent_qq_csv(fep):
+    g = load_golden('tsx')
+    K, B, w, Q = _tsx_ctx(fep, 'P1', g['coord'], g['elem'])
+    qf = Q.flatten(order='F')
+    Kqq = K[qf][:, qf].toarray()
+    ref = ssp.coo_matrix((g['p1_Kqq_val'], (g['p1_Kqq_row'], g['p1_Kqq_col'])), shape=(908, 908)).toarray()
+    assert relerr(Kqq, ref) <= TOL_K
+    csv = ssp.coo_matrix((g['kqq_val'], (g['kqq_row'], g['kqq_col'])), shape=(908, 908)).toarray()
+    assert not np.logical_and(csv != 0, Kqq == 0).any()                    # CSV pattern is covered
+    assert np.abs(Kqq - csv).max() <= 1e-4 * np.abs(csv).max()             # MATLAB dump, un-rounded coordinates
+
+
+def test_tsx_p2_load_vs_f0q_csv_and_p4(fep):
+    g = load_golden('tsx')
+    K, B, w, Q = _tsx_ctx(fep, 'P2', g['p2_coord'], g['p2_elem'])
+    s0 = np.array([-45.0, -11.0, 0.0, -60.0]).reshape((-1, 1)) * np.ones((1, w.size))
+    _, F0 = fep.assemble_tangent(K, None, s0)                              # TSX:1737
+    F0 = F0.reshape((2, -1), order='F')
+    assert relerr(F0, g['p2_F0']) <= TOL_K
+    assert np.abs(F0.T[Q.T] - g['f0q']).max() <= 2e-4 * np.abs(g['f0q']).max()
+    assert relerr(K.diagonal(), g['p2_K_diag']) <= TOL_K
+    K4, B4, w4, Q4 = _tsx_ctx(fep, 'P4', g['p4_coord'], g['p4_elem'])
+    assert relerr(K4.diagonal(), g['p4_K_diag']) <= 1e-11
+    assert abs(np.sqrt((K4.data ** 2).sum()) - g['p4_K_frob']) <= 1e-11 * g['p4_K_frob']
+    assert abs(w4.sum() - g['p4_weight_sum']) <= 1e-13 * g['p4_weight_sum']
+
+
+def test_tsx_p1_replay_state_vs_reference(fep):
+    """Hot path on the reference's converged TSX displacement (step 17, 3 plastic points)."""
+    g = load_golden('tsx')
+    coord, elem = g['coord'], g['elem']
+    n_int = elem.shape[1]
+    G = 60000 / (2 * (1 + 0.2)) * np.ones(n_int)
+    Kb = 60000 / (3 * (1 - 2 * 0.2)) * np.ones(n_int)
+    fr = 49 * np.pi / 180
+    eta = 3 * np.tan(fr) / np.sqrt(9 + 12 * np.tan(fr) ** 2) * np.ones(n_int)
+    c = 3 * 18.7 / np.sqrt(9 + 12 * np.tan(fr) ** 2) * np.ones(n_int)
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(G, Kb, eta, c)
+    r = ctx.step(g['p1_U_final'], np.zeros((4, n_int)), e0=1.0 * g['init_strain'], want=('ind_p', 's', 'K', 'F'))
+    assert int(r['ind_p'].sum()) == int(g['p1_nplast'][-1]) == 3
+    d1, d2, wf = tables('dp', 'P1')
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, G, Kb, d1, d2, wf)
+    E, cp, K_t, F = orc.hot_path(g['p1_U_final'], np.zeros((4, n_int)),
+                                 dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=G, bulk=Kb, eta=eta, c=c),
+                                 e0=1.0 * g['init_strain'], tsx=True)
+    assert np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['K'].toarray(), K_t.toarray()) <= TOL_K and relerr(r['F'], F) <= TOL_K
+    # converged state: residual on the free DOFs vanishes (fq.csv is ~1e-15)
+    Q = np.ones(coord.shape, dtype=bool)
+    Q[0, np.abs(coord[0]) > 49.99] = 0
+    Q[1, np.abs(coord[1]) > 49.99] = 0
+    assert np.abs(r['F'][Q.flatten(order='F')]).max() <= 1e-9 * np.abs(r['F']).max()
+
+
+# ---- config 1: Elasticity2D P1 K ----------------------------------------------------------
+@pytest.mark.parametrize('level,nnz,trace,frob', [(1, 7680, 4.215902547065e+08, 2.054604152327e+07),
+                                                 (3, 117120, 6.745444075305e+09, 8.396141008266e+07)])
+def test_el_p1_K_pins(fep, level, nnz, trace, frob):
+    g = load_golden('el_p1')
+    d1, d2, wf = tables('dp', 'P1')
+    elem1 = g[f'l{level}_elements_1based'].astype(np.int64)
+    coord = g[f'l{level}_coordinates']
+    n_int = elem1.shape[1]
+    G = 206900 / (2 * (1 + 0.29)) * np.ones(n_int)
+    Kb = 206900 / (3 * (1 - 2 * 0.29)) * np.ones(n_int)
+    K, w = fep.elasticity2d.get_elastic_stiffness_matrix(elem1, coord, G, Kb, d1, d2, wf)
+    assert elem1.min() == 0                                       # shifted in place like EL:389
+    Kz = K.copy()
+    Kz.data[np.abs(Kz.data) < 1e-9 * np.abs(Kz.data).max()] = 0   # SciPy drops exact zeros (C9)
+    Kz.eliminate_zeros()
+    assert Kz.nnz == nnz
+    assert abs(K.diagonal().sum() - trace) <= 1e-12 * trace
+    assert abs(np.sqrt((K.data ** 2).sum()) - frob) <= 1e-12 * frob
+    assert abs(w.sum() - 75.0) <= 1e-12 * 75
+    assert relerr(K @ np.cos(np.arange(K.shape[0]) * 0.37), g[f'l{level}_Kx']) <= TOL_K
+
+
+# ---- mid size vs oracle, every element type ------------------------------------------------
+@pytest.mark.parametrize('t,N', [('P1', 60), ('P2', 24), ('Q1', 40), ('Q2', 20)])
+def test_hot_path_mid_size_vs_oracle(fep, t, N):
+    rng = np.random.default_rng(5)
+    mesh = fep.square_mesh(N, t, 10)
+    elem, coord = mesh['elements'], mesh['coordinates'].copy()
+    inner = np.logical_and.reduce([coord[0] > 0, coord[0] < 10, coord[1] > 0, coord[1] < 10])
+    coord[:, inner] += rng.uniform(-0.1, 0.1, size=(2, inner.sum())) * (10 / N) / (2 if t in ('P2', 'Q2') else 1)
+    d1, d2, wf = fep.element_tables(t)
+    n_int = elem.shape[1] * NQ[t]
+    sh, bu, eta, c = dp_materials(n_int)
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    U += rng.normal(0, 3e-6, size=U.shape)
+    Ep = rng.normal(0, 5e-6, size=(4, n_int))
+    ctx = fep.MeshContext(elem, coord, d1, d2, wf)
+    ctx.set_materials(sh, bu, eta, c)
+    ep = Ep.copy()
+    r = ctx.step(U, ep, apply_plastic_strain=True, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)
+    ep_o = Ep.copy()
+    E, cp, K_t, F = orc.hot_path(U, ep_o, dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=sh, bulk=bu,
+                                                eta=eta, c=c), apply_plastic_strain=True)
+    assert 0 < cp['n_smooth'] and 0 < cp['n_apex'] < 20000 and cp['n_smooth'] + cp['n_apex'] < n_int
+    assert (r['n_smooth'], r['n_apex']) == (cp['n_smooth'], cp['n_apex'])
+    assert np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['E'], E) <= 1e-13
+    assert relerr(r['s'], cp['s']) <= TOL_PT and relerr(r['ds'], cp['ds']) <= TOL_PT and relerr(ep, ep_o) <= TOL_PT
+    diff = (r['K'] - K_t)
+    assert np.abs(diff.data).max() <= TOL_K * np.abs(K_t.data).max()
+    assert relerr(r['F'], F) <= TOL_K
+
+
+# ---- full benchmark size: properties (the reference cannot run here: DP:714 needs n_apex^2 memory) ----
+def test_full_size_p1_properties(fep):
+    N = 708                                                   # 1 002 528 P1 elements (config 4)
+    mesh = fep.square_mesh(N, 'P1', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n_e = elem.shape[1]
+    assert n_e == 1002528
+    sh, bu, eta, c = dp_materials(n_e)
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh, bu, eta, c)
+    _, _, w, det = ctx.geometry()
+    assert abs(w.sum() - 100.0) <= 1e-9                       # sum of weights = area
+    assert (det > 0).all()
+    # (1) all elastic: K_tangent == K_elast, F == K_elast U
+    rng = np.random.default_rng(1)
+    U0 = rng.normal(0, 1e-9, size=(2, coord.shape[1]))
+    r0 = ctx.step(U0, want=('K', 'F', 'ind_p'))
+    assert not r0['ind_p'].any()
+    Kel = ctx.step(np.zeros_like(U0), want=('K',))['K']
+    assert np.array_equal(r0['K'].data, Kel.data)
+    assert relerr(r0['F'], Kel @ U0.reshape(-1, order='F')) <= 1e-10
+    assert np.abs(Kel - Kel.T).data.max() <= 1e-12 * np.abs(Kel.data).max()     # symmetry
+    rigid = np.tile([1.0, 0.0], coord.shape[1])
+    assert np.abs(Kel @ rigid).max() <= 1e-9 * np.abs(Kel.data).max()           # translations in the kernel
+    # (2) mixed state: sampled elements against the oracle's per-point map + symmetric tangent
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    U += rng.normal(0, 2e-8, size=U.shape)
+    r = ctx.step(U, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    assert r['n_smooth'] > 1e5 and r['n_apex'] > 1e4 and r['n_smooth'] + r['n_apex'] < n_e
+    sel = rng.choice(n_e, 4000, replace=False)
+    o = orc.return_map(r['E'][:, sel], None, sh[sel], bu[sel], eta[sel], c[sel])
+    assert np.array_equal(o['ind_p'], r['ind_p'][sel])
+    assert relerr(r['s'][:, sel], o['s']) <= TOL_PT and relerr(r['ds'][:, sel], o['ds']) <= TOL_PT
+    Kt = r['K']
+    assert np.abs(Kt - Kt.T).data.max() <= 1e-12 * np.abs(Kt.data).max()
+    assert np.abs(Kt @ rigid).max() <= 1e-9 * np.abs(Kt.data).max()
+    # F is linear in s: F(s) from the unfused route equals the fused one bit for bit
+    _, F2 = ctx.assemble(None, r['s'])
+    assert np.array_equal(F2, r['F'])
+    # strain of sampled elements against a direct evaluation
+    d1, d2, wgt, _ = ctx.geometry()
+    nodes = elem[:, sel]
+    ux, uy = U[0][nodes], U[1][nodes]
+    E_dir = np.array([(d1[:, sel] * ux).sum(0), (d2[:, sel] * uy).sum(0), (d2[:, sel] * ux + d1[:, sel] * uy).sum(0)])
+    assert relerr(r['E'][:, sel], E_dir) <= 1e-13
+    ctx.close()
+
+
+def test_error_codes(fep):
+    elem = np.array([[0], [1], [5]])                      # node id out of range
+    coord = np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    with pytest.raises(IndexError):
+        fep.MeshContext(elem, coord)
+    import ctypes as C
+    l = fep.lib()
+    h = C.c_void_p()
+    el32 = np.array([[0], [1], [7]], dtype=np.int32)
+    d1, d2, wf = fep.element_tables('P1')
+    rc = l.fep_ctx_create(C.byref(h), 0, 1, 1, 3, el32.ctypes.data, coord.ctypes.data, d1.ctypes.data, d2.ctypes.data,
+                          wf.ctypes.data)
+    assert rc == -5 and not h                             # FEP_ERANGE, no context
+    assert l.fep_ctx_create(C.byref(h), 0, 9, 1, 3, el32.ctypes.data, coord.ctypes.data, d1.ctypes.data, d2.ctypes.data,
+                            wf.ctypes.data) == -1        # unknown element type
+    ctx = fep.MeshContext(np.array([[0], [1], [2]]), coord)
+    with pytest.raises(fep.FepError):                     # materials not set -> FEP_ESTATE
+        ctx.step(np.zeros(6))
