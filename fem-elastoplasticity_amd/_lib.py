@@ -47,9 +47,8 @@ PROTOTYPES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'fep_step_kernel_names': (C.c_char_p, [C.c_void_p]),
-    'fep_step_kernel_time': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    'fep_ctx_profile_begin': (C.c_int, [C.c_void_p]),
+    'fep_ctx_profile_end': (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
 }
 
 

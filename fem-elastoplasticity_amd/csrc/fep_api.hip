@@ -42,11 +42,23 @@ struct fep_ctx {
     double *shear = nullptr, *bulk = nullptr, *eta = nullptr, *c = nullptr;
     int32_t *segptr = nullptr, *perm = nullptr, *iptr = nullptr, *ilist = nullptr;
     uint32_t* meta = nullptr;
+    // P1 fast path (node-centric gather assembly): 64-byte geometry records, re-encoded gather list
+    bool p1_node = false, p1_lds = false;
+    double* geo = nullptr;
+    int32_t *perm2 = nullptr, *ncol = nullptr;
+    int32_t *wg_eptr = nullptr, *wg_elist = nullptr;   // LDS-staged variant: per-workgroup element lists
+    uint16_t* perm_l = nullptr;
+    int lds_L = 0;
     // device, scratch rewritten by every step
     double *Kc = nullptr, *fe = nullptr;
-    unsigned long long* counts = nullptr;
+    double *s_int = nullptr, *ds_int = nullptr;     // used when the caller does not ask for s / ds
+    uint2* blk_counts = nullptr;
+    int n_count_blocks = 0;
     // host copies of the pattern
     std::vector<int32_t> indptr, indices;
+    // in-situ profiling: 4 events per step (before element, after element, after csr, after force)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
 };
 
 static int set_device(int dev) {
@@ -282,7 +294,7 @@ static int build_symbolic(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem
     S.nptr.assign(n_n + 1, 0);
     int64_t tot = 0;
     for (int64_t n = 0; n < n_n; ++n) {
-        if (deg[n] > 0xffff) return FEP_ERANGE;
+        if (deg[n] > 0x7fff) return FEP_ERANGE;
         tot += deg[n];
         if (tot >= INT32_MAX / 4) return FEP_ERANGE;
         S.nptr[n + 1] = (int32_t)tot;
@@ -308,7 +320,7 @@ static int build_symbolic(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem
                             ++slot;
                             const int64_t blk = S.nptr[n] + slot;
                             S.ncol[blk] = buf[i].first;
-                            S.meta[blk] = ((uint32_t)deg[n] << 16) | (uint32_t)slot;
+                            S.meta[blk] = ((uint32_t)deg[n] << 16) | (buf[i].first == (int32_t)n ? 0x8000u : 0u) | (uint32_t)slot;
                             S.segptr[blk] = (int32_t)pos;
                         }
                         S.perm[pos++] = buf[i].second;
@@ -324,7 +336,8 @@ static int build_symbolic(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem
 template <int NP, int NQ>
 static int launch_geometry(fep_ctx* c) {
     hipLaunchKernelGGL((geometry_kernel<NP, NQ>), dim3(grid_for(c->n_int, kBlock)), dim3(kBlock), 0, nullptr,
-                       c->n_e, c->n_n, c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det);
+                       c->n_e, c->n_n, c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det,
+                       c->geo);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }
@@ -343,9 +356,11 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (!c) return FEP_OK;
     if (set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
-                        c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->counts};
+                        c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->perm_l};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
+        for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
     }
     delete c;
     return FEP_OK;
@@ -396,13 +411,79 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     CK(dmalloc(&c->det, c->n_int));
     CK(dmalloc(&c->shear, c->n_int)); CK(dmalloc(&c->bulk, c->n_int)); CK(dmalloc(&c->eta, c->n_int)); CK(dmalloc(&c->c, c->n_int));
     CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
-    CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
     CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
-    CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
-    CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
-    CK(dmalloc(&c->Kc, 4 * c->n_contrib));
-    CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
-    CK(dmalloc(&c->counts, 2));
+    {   // P1 runs the node-centric fast path unless FEP_P1_PATH=coo asks for the generic COO route
+        const char* pth = std::getenv("FEP_P1_PATH");
+        c->p1_node = elem_type == FEP_P1 && !(pth && std::strcmp(pth, "coo") == 0);
+    }
+    if (c->p1_node) {
+        if (n_e >= (int64_t)1 << 27) r = FEP_ERANGE;
+        std::vector<int32_t> perm2(S.perm.size());
+        for (size_t i = 0; i < S.perm.size(); ++i) {
+            const int64_t code = S.perm[i];
+            const int64_t ab = code / n_e, e = code - ab * n_e;
+            perm2[i] = (int32_t)((e << 4) | ((ab / 3) << 2) | (ab % 3));
+        }
+        CK(upload(&c->perm2, perm2.data(), (int64_t)perm2.size()));
+        CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
+        {   // per-workgroup (256 consecutive blocks) sorted unique element lists + local gather codes
+            const int64_t n_wg = (c->n_blk + kBlock - 1) / kBlock;
+            std::vector<int32_t> eptr(n_wg + 1, 0);
+            std::vector<std::vector<int32_t>> lists(n_wg);
+            std::vector<uint16_t> perm_l(perm2.size());
+            const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> th;
+            for (int w = 0; w < nthreads; ++w)
+                th.emplace_back([&, w]() {
+                    for (int64_t g = n_wg * w / nthreads; g < n_wg * (w + 1) / nthreads; ++g) {
+                        const int64_t b0 = g * kBlock, b1 = std::min<int64_t>(c->n_blk, b0 + kBlock);
+                        const int32_t t0 = S.segptr[b0], t1 = S.segptr[b1];
+                        std::vector<int32_t>& l = lists[g];
+                        l.reserve(t1 - t0);
+                        for (int32_t t = t0; t < t1; ++t) l.push_back(perm2[t] >> 4);
+                        std::sort(l.begin(), l.end());
+                        l.erase(std::unique(l.begin(), l.end()), l.end());
+                        for (int32_t t = t0; t < t1; ++t) {
+                            const int32_t loc = (int32_t)(std::lower_bound(l.begin(), l.end(), perm2[t] >> 4) - l.begin());
+                            perm_l[t] = (uint16_t)((loc << 4) | (perm2[t] & 15));
+                        }
+                    }
+                });
+            for (auto& t : th) t.join();
+            size_t lmax = 0;
+            for (int64_t g = 0; g < n_wg; ++g) { eptr[g + 1] = eptr[g] + (int32_t)lists[g].size(); lmax = std::max(lmax, lists[g].size()); }
+            std::vector<int32_t> elist((size_t)eptr[n_wg]);
+            for (int64_t g = 0; g < n_wg; ++g) std::copy(lists[g].begin(), lists[g].end(), elist.begin() + eptr[g]);
+            const char* pth = std::getenv("FEP_P1_PATH");
+            c->lds_L = (int)((lmax + 1) & ~(size_t)1);
+            // 15 doubles per staged element; fall back to the direct-gather kernel when a list would not fit
+            c->p1_lds = lmax < 4096 && (size_t)c->lds_L * 15 * sizeof(double) <= 96 * 1024 &&
+                        !(pth && std::strcmp(pth, "node_direct") == 0);
+            if (c->p1_lds) {
+                CK(upload(&c->wg_eptr, eptr.data(), (int64_t)eptr.size()));
+                CK(upload(&c->wg_elist, elist.data(), (int64_t)elist.size()));
+                CK(upload(&c->perm_l, perm_l.data(), (int64_t)perm_l.size()));
+            }
+        }
+        CK(dmalloc(&c->geo, 8 * n_e));
+        c->n_count_blocks = (int)grid_for(n_e, kBlock);
+    } else {
+        CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
+        CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
+        CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
+        CK(dmalloc(&c->Kc, 4 * c->n_contrib));
+        CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
+        int eb = 1;
+        switch (elem_type) {
+            case FEP_P1: eb = ElemCfg<3, 1>::EB; break;
+            case FEP_P2: eb = ElemCfg<6, 7>::EB; break;
+            case FEP_Q1: eb = ElemCfg<4, 4>::EB; break;
+            case FEP_Q2: eb = ElemCfg<8, 9>::EB; break;
+            case FEP_P4: eb = ElemCfg<15, 12>::EB; break;
+        }
+        c->n_count_blocks = (int)grid_for(n_e, eb);
+    }
+    CK(dmalloc(&c->blk_counts, c->n_count_blocks));
 #undef CK
     if (r == FEP_OK) {
 #define CALL(NP, NQ) r = launch_geometry<NP, NQ>(c)
@@ -477,30 +558,73 @@ extern "C" int fep_ctx_device_ptr(const fep_ctx* c, int which, void** ptr_d) {
 // ---------------------------------------------------------------------------------------
 // hot path
 // ---------------------------------------------------------------------------------------
+static int prof_mark(fep_ctx* c, hipStream_t st) {
+    if (!c->profiling) return FEP_OK;
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    c->events.push_back(ev);
+    HIP_TRY(hipEventRecord(ev, st));
+    return FEP_OK;
+}
+
 template <int NP, int NQ, bool FROM_U>
 static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept,
-                          double* eout, double* s, double* ds, uint8_t* indp, unsigned long long* counts,
+                          double* eout, double* s, double* ds, uint8_t* indp, uint2* blk_counts,
                           double* Kc, double* fe) {
     constexpr int EB = ElemCfg<NP, NQ>::EB;
     static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
     hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U>), dim3(grid_for(c->n_e, EB)), dim3(kBlock), 0, st,
                        c->n_e, c->elem, c->dphi1, c->dphi2, c->weight, u, e0, ep, c->shear, c->bulk, c->eta, c->c,
-                       accept, eout, s, ds, indp, counts, Kc, fe);
+                       accept, eout, s, ds, indp, blk_counts, Kc, fe);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }
 
+static int launch_counts(fep_ctx* c, hipStream_t st, unsigned long long* counts_d) {
+    if (!counts_d) return FEP_OK;
+    hipLaunchKernelGGL(counts_reduce_kernel, dim3(1), dim3(kBlock), 0, st, c->n_count_blocks, c->blk_counts, counts_d);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+// COO route, numeric phase: K_e blocks -> CSR values, f_e pairs -> nodal force
 static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_out) {
+    FEP_TRY(prof_mark(c, st));
     if (k_data) {
         hipLaunchKernelGGL(csr_reduce_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
                            c->n_blk, c->segptr, c->perm, c->meta, c->Kc, k_data);
         HIP_TRY(hipGetLastError());
     }
+    FEP_TRY(prof_mark(c, st));
     if (f_out) {
         hipLaunchKernelGGL(force_reduce_kernel, dim3(grid_for(c->n_n, kBlock)), dim3(kBlock), 0, st,
                            c->n_n, c->iptr, c->ilist, c->fe, f_out);
         HIP_TRY(hipGetLastError());
     }
+    FEP_TRY(prof_mark(c, st));
+    return FEP_OK;
+}
+
+// P1 node route, assembly kernel (reads ds / s, writes CSR values and nodal force)
+static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const double* s, double* k_data, double* f_out) {
+    FEP_TRY(prof_mark(c, st));
+    if ((k_data && ds) || (f_out && s)) {
+        if (c->p1_lds) {
+            const size_t lds = (size_t)c->lds_L * 15 * sizeof(double);
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(p1_node_lds_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), lds, st,
+                               c->n_blk, c->n_e, c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist,
+                               c->geo, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out);
+        } else {
+            hipLaunchKernelGGL(p1_node_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
+                               c->n_blk, c->n_e, c->segptr, c->perm2, c->meta, c->ncol, c->geo,
+                               k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    FEP_TRY(prof_mark(c, st));
+    FEP_TRY(prof_mark(c, st));
     return FEP_OK;
 }
 
@@ -512,14 +636,34 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
     FEP_TRY(set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* cnt = (unsigned long long*)counts_d;
-    if (cnt) HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int64_t), st));
+    uint2* blk = cnt ? c->blk_counts : nullptr;
     const E0 e0 = make_e0(e0_h);
+    if (c->p1_node) {
+        // the assembly kernel consumes ds / s from HBM: use internal buffers when the caller wants neither
+        if (k_data_d && !ds_d) {
+            if (!c->ds_int) FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int));
+            ds_d = c->ds_int;
+        }
+        if (f_out_d && !s_d) {
+            if (!c->s_int) FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int));
+            s_d = c->s_int;
+        }
+        FEP_TRY(prof_mark(c, st));
+        hipLaunchKernelGGL(p1_point_kernel, dim3(grid_for(c->n_e, kBlock)), dim3(kBlock), 0, st,
+                           c->n_e, c->elem, c->geo, u_d, e0, ep_prev_d, c->shear, c->bulk, c->eta, c->c, accept,
+                           e_out_d, s_d, ds_d, ind_p_d, blk);
+        HIP_TRY(hipGetLastError());
+        FEP_TRY(launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d));
+        return launch_counts(c, st, cnt);
+    }
+    FEP_TRY(prof_mark(c, st));
 #define CALL(NP, NQ)                                                                                     \
-    FEP_TRY((launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, cnt, \
+    FEP_TRY((launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk, \
                                           k_data_d ? c->Kc : nullptr, f_out_d ? c->fe : nullptr)))
     DISPATCH_ELEM(c->elem_type, CALL)
 #undef CALL
-    return launch_reduce(c, st, k_data_d, f_out_d);
+    FEP_TRY(launch_reduce(c, st, k_data_d, f_out_d));
+    return launch_counts(c, st, cnt);
 }
 
 extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, const double* s_d,
@@ -528,7 +672,12 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
     if ((k_data_d && !ds_d) || (f_out_d && !s_d)) return FEP_EINVAL;
     FEP_TRY(set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
+    if (c->p1_node) {
+        FEP_TRY(prof_mark(c, st));
+        return launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d);
+    }
     const E0 e0 = make_e0(nullptr);
+    FEP_TRY(prof_mark(c, st));
 #define CALL(NP, NQ)                                                                                         \
     FEP_TRY((launch_element<NP, NQ, false>(c, st, nullptr, e0, nullptr, 0, nullptr, const_cast<double*>(s_d), \
                                            const_cast<double*>(ds_d), nullptr, nullptr,                      \
@@ -585,42 +734,31 @@ extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s
     return FEP_OK;
 }
 
-extern "C" const char* fep_step_kernel_names(const fep_ctx*) {
-    return "element_kernel\0csr_reduce_kernel\0force_reduce_kernel\0";
+extern "C" int fep_ctx_profile_begin(fep_ctx* c) {
+    if (!c) return FEP_EINVAL;
+    for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+    c->events.clear();
+    c->profiling = true;
+    return FEP_OK;
 }
 
-extern "C" int fep_step_kernel_time(fep_ctx* c, void* stream, int reps, const double* u_d, const double* e0_h,
-                                    double* ep_prev_d, double* s_d, double* ds_d, uint8_t* ind_p_d, float* ms_out) {
-    if (!c || !u_d || !ms_out || reps <= 0) return FEP_EINVAL;
-    if (!c->have_materials) return FEP_ESTATE;
+extern "C" int fep_ctx_profile_end(fep_ctx* c, void* stream, double ms_out[3], int* n_steps) {
+    if (!c || !ms_out) return FEP_EINVAL;
+    c->profiling = false;
     FEP_TRY(set_device(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    hipEvent_t ev0, ev1;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    const E0 e0 = make_e0(e0_h);
-    int r = FEP_OK;
-    (void)hipEventRecord(ev0, st);
-    for (int i = 0; i < reps && r == FEP_OK; ++i) {
-#define CALL(NP, NQ) \
-    r = launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, 0, nullptr, s_d, ds_d, ind_p_d, nullptr, c->Kc, c->fe)
-        switch (c->elem_type) {
-            case FEP_P1: CALL(3, 1); break;
-            case FEP_P2: CALL(6, 7); break;
-            case FEP_Q1: CALL(4, 4); break;
-            case FEP_Q2: CALL(8, 9); break;
-            case FEP_P4: CALL(15, 12); break;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int n = (int)(c->events.size() / 4);
+    for (int s = 0; s < n && e == hipSuccess; ++s)
+        for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, c->events[4 * s + k], c->events[4 * s + k + 1]);
+            acc[k] += ms;
         }
-#undef CALL
-    }
-    (void)hipEventRecord(ev1, st);
-    hipError_t e = hipEventSynchronize(ev1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    if (r != FEP_OK) return r;
-    if (e != hipSuccess) { g_last_hip = (int)e; return FEP_EHIP; }
-    *ms_out = ms / (float)reps;
+    for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+    c->events.clear();
+    if (e != hipSuccess) { g_last_hip = (int)e; (void)hipGetLastError(); return FEP_EHIP; }
+    for (int k = 0; k < 3; ++k) ms_out[k] = n ? acc[k] / n : 0.0;
+    if (n_steps) *n_steps = n;
     return FEP_OK;
 }

@@ -90,15 +90,45 @@ __device__ __forceinline__ int dp_return_map(const double e[3], const double z[4
     return branch;
 }
 
-// one atomic per wave for the smooth / apex counters (integer => deterministic)
-__device__ __forceinline__ void count_branches(int branch, unsigned long long* counts) {
-    if (counts == nullptr) return;
+// Smooth / apex counters (the numbers the reference logs at DP:730).  Wave ballot -> LDS -> per
+// workgroup either a plain store into blk_counts[blockIdx.x] (summed by counts_reduce_kernel; no
+// global atomics at all) or, for the mesh-free entry point, one global atomic per workgroup.
+// Integer sums => deterministic.  Must be reached by every thread of the block.
+__device__ __forceinline__ void count_branches(int branch, unsigned long long* counts, uint2* blk_counts) {
+    if (counts == nullptr && blk_counts == nullptr) return;       // uniform
+    __shared__ unsigned int sc[2];
+    if (threadIdx.x == 0) { sc[0] = 0u; sc[1] = 0u; }
+    __syncthreads();
     const unsigned long long ms = __ballot(branch == 1);
     const unsigned long long ma = __ballot(branch == 2);
     if ((threadIdx.x & 63) == 0) {
-        if (ms) atomicAdd(&counts[0], (unsigned long long)__popcll(ms));
-        if (ma) atomicAdd(&counts[1], (unsigned long long)__popcll(ma));
+        if (ms) atomicAdd(&sc[0], (unsigned int)__popcll(ms));
+        if (ma) atomicAdd(&sc[1], (unsigned int)__popcll(ma));
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blk_counts) {
+            blk_counts[blockIdx.x] = make_uint2(sc[0], sc[1]);
+        } else {
+            if (sc[0]) atomicAdd(&counts[0], (unsigned long long)sc[0]);
+            if (sc[1]) atomicAdd(&counts[1], (unsigned long long)sc[1]);
+        }
+    }
+}
+
+// counts_out[0..1] = sum of blk_counts[0..n_blocks): one workgroup, overwrites (no memset needed)
+__global__ void __launch_bounds__(kBlock)
+counts_reduce_kernel(int n_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
+    __shared__ unsigned long long acc[2][kBlock];
+    unsigned long long a = 0, b = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += kBlock) { const uint2 v = blk_counts[i]; a += v.x; b += v.y; }
+    acc[0][threadIdx.x] = a; acc[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { acc[0][threadIdx.x] += acc[0][threadIdx.x + s]; acc[1][threadIdx.x] += acc[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counts_out[0] = acc[0][0]; counts_out[1] = acc[1][0]; }
 }
 
 __device__ __forceinline__ void store_point(int64_t k, int64_t n, const double s[4], const double d[6], int branch,
@@ -135,7 +165,7 @@ return_map_kernel(int64_t n, const double* __restrict__ e, int64_t eps, int64_t 
         store_point(k, n, s, d, branch, S, DS, indp);
         if (accept && ep && branch) { ep[k] = p[0]; ep[n + k] = p[1]; ep[2 * n + k] = p[2]; ep[3 * n + k] = p[3]; }
     }
-    count_branches(branch, counts);
+    count_branches(branch, counts, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -148,7 +178,7 @@ __global__ void __launch_bounds__(kBlock)
 geometry_kernel(int64_t n_e, int64_t n_n, const int32_t* __restrict__ elem, const double* __restrict__ coords,
                 const double* __restrict__ dh1, const double* __restrict__ dh2, const double* __restrict__ wf,
                 double* __restrict__ dphi1, double* __restrict__ dphi2, double* __restrict__ weight,
-                double* __restrict__ det_out) {
+                double* __restrict__ det_out, double* __restrict__ geo) {
 #pragma clang fp contract(off)
     __shared__ double t1[NP * NQ], t2[NP * NQ], tw[NQ];
     for (int i = threadIdx.x; i < NP * NQ; i += kBlock) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
@@ -175,6 +205,16 @@ geometry_kernel(int64_t n_e, int64_t n_n, const int32_t* __restrict__ elem, cons
     }
     weight[k] = fabs(det) * tw[q];                       // DP:585
     if (det_out) det_out[k] = det;
+    if (NP == 3 && NQ == 1 && geo) {                     // AoS record of the P1 fast path: d1[3], d2[3], w, 0
+        double* g = geo + k * 8;
+        for (int a = 0; a < NP; ++a) {
+            const double h1 = t1[a * NQ + q], h2 = t2[a * NQ + q];
+            g[a] = i11 * h1 + i12 * h2;
+            g[3 + a] = i21 * h1 + i22 * h2;
+        }
+        g[6] = fabs(det) * tw[q];
+        g[7] = 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -205,7 +245,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                const double* __restrict__ eta, const double* __restrict__ cc, int accept,
                // outputs of phase 1 (FROM_U) or inputs (!FROM_U)
                double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
-               unsigned long long* counts,
+               uint2* blk_counts,
                // outputs of phase 2
                double* __restrict__ Kc, double* __restrict__ fe) {
     using C = ElemCfg<NP, NQ>;
@@ -270,7 +310,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         for (int m = 0; m < 6; ++m) Ds[m][li] = w * d[m];                        // vD = w*ds, DP:1047
         Ss[0][li] = w * s[0]; Ss[1][li] = w * s[1]; Ss[2][li] = w * s[2];        // DP:1058
     }
-    if (FROM_U) count_branches(branch, counts);
+    if (FROM_U) count_branches(branch, nullptr, blk_counts);
     __syncthreads();
 
     // ---- phase 2 --------------------------------------------------------------------
@@ -316,7 +356,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 // ---------------------------------------------------------------------------------------
 // Numeric COO -> CSR phase: one lane per node-pair block (row node n, neighbour slot s).
 // Deterministic: contributions are summed in the fixed order of `perm` (no atomics).
-//   segptr[n_blk+1], perm[...] = (a*NP+b)*n_e + e,  meta[blk] = (deg(n) << 16) | s
+//   segptr[n_blk+1], perm[...] = (a*NP+b)*n_e + e,  meta[blk] = (deg(n) << 16) | (diag << 15) | s
 //   CSR data: row 2n+i starts at 4*nptr[n] + i*2*deg, entry (slot s, comp j) at + 2s + j.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -332,7 +372,7 @@ csr_reduce_kernel(int64_t n_blk, const int32_t* __restrict__ segptr, const int32
         a00 += r0.x; a01 += r0.y; a10 += r1.x; a11 += r1.y;
     }
     const uint32_t m = meta[sb];
-    const int64_t s = m & 0xffffu, deg = m >> 16;
+    const int64_t s = m & 0x7fffu, deg = m >> 16;
     const int64_t pos0 = 4 * sb - 2 * s;
     *reinterpret_cast<double2*>(data + pos0) = make_double2(a00, a01);
     *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(a10, a11);
@@ -350,6 +390,163 @@ force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t
         f0 += v.x; f1 += v.y;
     }
     *reinterpret_cast<double2*>(F + 2 * n) = make_double2(f0, f1);
+}
+
+// ---------------------------------------------------------------------------------------
+// P1 fast path (3-node triangle, 1 integration point): no element-matrix round trip through HBM.
+//
+//   p1_point_kernel   one lane per element: strain from U (a1) + return map (a2); writes s, ds, ind_p.
+//   p1_node_kernel    one lane per node-pair block of the CSR pattern: gathers, for every element that
+//                     contributes to the block, its tangent (6 values of ds), weight and the two nodes'
+//                     dphi, forms the 2x2 block  w * B_a^T DS B_b  on the fly and sums in the fixed
+//                     order of `perm2` (a3, a4); the lane that owns the diagonal block of a node also
+//                     sums the node's internal force  w * B_a^T s  (a5).  No atomics, no COO buffer.
+//
+//   geo[e*8 + {0,1,2}] = dphi_1 of the 3 nodes, {3,4,5} = dphi_2, [6] = weight (64-byte record)
+//   perm2[t] = e*16 + a*4 + b ;  meta = (deg << 16) | (diag << 15) | slot
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+p1_point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __restrict__ geo,
+                const double* __restrict__ U, E0 e0, double* __restrict__ ep,
+                const double* __restrict__ shear, const double* __restrict__ bulk,
+                const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+                double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS,
+                uint8_t* __restrict__ indp, uint2* blk_counts) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int branch = 0;
+    if (e < n_e) {
+        const int64_t n0 = elem[e], n1 = elem[n_e + e], n2 = elem[2 * n_e + e];
+        const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
+        const double2 g0 = g[0], g1 = g[1], g2 = g[2];          // (d1_0,d1_1) (d1_2,d2_0) (d2_1,d2_2)
+        const double2 u0 = *reinterpret_cast<const double2*>(U + 2 * n0);
+        const double2 u1 = *reinterpret_cast<const double2*>(U + 2 * n1);
+        const double2 u2 = *reinterpret_cast<const double2*>(U + 2 * n2);
+        double ev[3];                                            // DP:1043, local node order
+        ev[0] = g0.x * u0.x + g0.y * u1.x + g1.x * u2.x;
+        ev[1] = g1.y * u0.y + g2.x * u1.y + g2.y * u2.y;
+        ev[2] = (g1.y * u0.x + g0.x * u0.y) + (g2.x * u1.x + g0.y * u1.y) + (g2.y * u2.x + g1.x * u2.y);
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ep) { p[0] = ep[e]; p[1] = ep[n_e + e]; p[2] = ep[2 * n_e + e]; p[3] = ep[3 * n_e + e]; }
+        double s[4], d[6];
+        branch = dp_return_map(ev, e0.v, p, shear[e], bulk[e], eta[e], cc[e], accept != 0, s, d);
+        store_point(e, n_e, s, d, branch, S, DS, indp);
+        if (Eout) { Eout[e] = ev[0]; Eout[n_e + e] = ev[1]; Eout[2 * n_e + e] = ev[2]; }
+        if (accept && ep && branch) { ep[e] = p[0]; ep[n_e + e] = p[1]; ep[2 * n_e + e] = p[2]; ep[3 * n_e + e] = p[3]; }
+    }
+    count_branches(branch, nullptr, blk_counts);
+}
+
+__global__ void __launch_bounds__(kBlock)
+p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, const int32_t* __restrict__ perm2,
+               const uint32_t* __restrict__ meta, const int32_t* __restrict__ ncol,
+               const double* __restrict__ geo, const double* __restrict__ DS, const double* __restrict__ S,
+               double* __restrict__ data, double* __restrict__ F) {
+    const int64_t sb = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (sb >= n_blk) return;
+    const int32_t beg = segptr[sb], end = segptr[sb + 1];
+    const uint32_t m = meta[sb];
+    const bool diag = (m >> 15) & 1u;
+    const bool want_f = diag && F != nullptr && S != nullptr;
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
+    for (int32_t t = beg; t < end; ++t) {
+        const uint32_t code = (uint32_t)perm2[t];
+        const int64_t e = code >> 4;
+        const int a = (code >> 2) & 3, b = code & 3;
+        const double* g = geo + e * 8;
+        const double a1 = g[a], a2 = g[3 + a], b1 = g[b], b2 = g[3 + b], w = g[6];
+        if (DS) {
+            const double D00 = DS[e], D01 = DS[n_e + e], D02 = DS[2 * n_e + e];
+            const double D11 = DS[4 * n_e + e], D12 = DS[5 * n_e + e], D22 = DS[8 * n_e + e];
+            // rows of B_a^T D:  r0 = (a1,0,a2) D,  r1 = (0,a2,a1) D                         DP:1047-1050
+            const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
+            const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+            k00 += w * (r00 * b1 + r02 * b2);
+            k01 += w * (r01 * b2 + r02 * b1);
+            k10 += w * (r10 * b1 + r12 * b2);
+            k11 += w * (r11 * b2 + r12 * b1);
+        }
+        if (want_f) {                                                                       // DP:1058
+            const double s0 = S[e], s1 = S[n_e + e], s2 = S[2 * n_e + e];
+            f0 += w * (a1 * s0 + a2 * s2);
+            f1 += w * (a2 * s1 + a1 * s2);
+        }
+    }
+    if (data) {
+        const int64_t s = m & 0x7fffu, deg = m >> 16;
+        const int64_t pos0 = 4 * sb - 2 * s;
+        *reinterpret_cast<double2*>(data + pos0) = make_double2(k00, k01);
+        *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(k10, k11);
+    }
+    if (want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol[sb]) = make_double2(f0, f1);
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-staged variant of p1_node_kernel (the default).  Uncoalesced 8-byte gathers cost one L1
+// (TCP) cycle per lane, which bounds the direct kernel (~100 M lane-loads per launch at 1 M
+// elements).  Here each workgroup (256 consecutive node-pair blocks = ~36 consecutive nodes)
+// first stages the per-element operands of the elements it touches — w*D (6), w*s (3), dphi (6) —
+// into LDS with coalesced loads over its precomputed, sorted element list, then every lane
+// gathers from LDS only.
+//   wg_eptr[n_wg+1], wg_elist[...]   sorted unique elements per workgroup
+//   perm_l[t] = (local element index << 4) | a << 2 | b      (uint16)
+//   LDS: rec[15][L], L = max list length (dynamic shared memory)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict__ segptr,
+                   const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
+                   const int32_t* __restrict__ ncol, const int32_t* __restrict__ wg_eptr,
+                   const int32_t* __restrict__ wg_elist, const double* __restrict__ geo,
+                   const double* __restrict__ DS, const double* __restrict__ S,
+                   double* __restrict__ data, double* __restrict__ F) {
+    extern __shared__ __attribute__((aligned(16))) double rec[];      // [15][L]
+    const int ebeg = wg_eptr[blockIdx.x], ecnt = wg_eptr[blockIdx.x + 1] - ebeg;
+    for (int i = threadIdx.x; i < ecnt; i += kBlock) {
+        const int64_t e = wg_elist[ebeg + i];
+        const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
+        const double2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+        const double w = g3.x;
+        rec[9 * L + i] = g0.x;  rec[10 * L + i] = g0.y; rec[11 * L + i] = g1.x;     // d1[0..2]
+        rec[12 * L + i] = g1.y; rec[13 * L + i] = g2.x; rec[14 * L + i] = g2.y;     // d2[0..2]
+        if (DS) {
+            rec[i] = w * DS[e];                 rec[L + i] = w * DS[n_e + e];      rec[2 * L + i] = w * DS[2 * n_e + e];
+            rec[3 * L + i] = w * DS[4 * n_e + e]; rec[4 * L + i] = w * DS[5 * n_e + e]; rec[5 * L + i] = w * DS[8 * n_e + e];
+        }
+        if (S) { rec[6 * L + i] = w * S[e]; rec[7 * L + i] = w * S[n_e + e]; rec[8 * L + i] = w * S[2 * n_e + e]; }
+    }
+    __syncthreads();
+    const int64_t sb = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (sb >= n_blk) return;
+    const int32_t beg = segptr[sb], end = segptr[sb + 1];
+    const uint32_t m = meta[sb];
+    const bool want_f = ((m >> 15) & 1u) && F != nullptr && S != nullptr;
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
+    for (int32_t t = beg; t < end; ++t) {
+        const unsigned code = perm_l[t];
+        const int i = code >> 4, a = (code >> 2) & 3, b = code & 3;
+        const double a1 = rec[(9 + a) * L + i], a2 = rec[(12 + a) * L + i];
+        const double b1 = rec[(9 + b) * L + i], b2 = rec[(12 + b) * L + i];
+        if (DS) {
+            const double D00 = rec[i], D01 = rec[L + i], D02 = rec[2 * L + i];
+            const double D11 = rec[3 * L + i], D12 = rec[4 * L + i], D22 = rec[5 * L + i];
+            const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
+            const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+            k00 += r00 * b1 + r02 * b2;
+            k01 += r01 * b2 + r02 * b1;
+            k10 += r10 * b1 + r12 * b2;
+            k11 += r11 * b2 + r12 * b1;
+        }
+        if (want_f) {
+            f0 += a1 * rec[6 * L + i] + a2 * rec[8 * L + i];
+            f1 += a2 * rec[7 * L + i] + a1 * rec[8 * L + i];
+        }
+    }
+    if (data) {
+        const int64_t s = m & 0x7fffu, deg = m >> 16;
+        const int64_t pos0 = 4 * sb - 2 * s;
+        *reinterpret_cast<double2*>(data + pos0) = make_double2(k00, k01);
+        *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(k10, k11);
+    }
+    if (want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol[sb]) = make_double2(f0, f1);
 }
 
 }  // namespace fep

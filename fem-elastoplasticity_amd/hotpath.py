@@ -264,13 +264,16 @@ class MeshContext:
         _lib.check(_lib.lib().fep_assemble_dev(self._h, stream, ds or None, s or None, k_data or None, f_out or None),
                    'fep_assemble_dev')
 
-    def kernel_time_ms(self, stream, reps, u, ep=0, s=0, ds=0, ind_p=0, e0=None):
-        """Average ms per launch of the fused element kernel alone (HIP events on `stream`)."""
-        ms = C.c_float()
-        e0v = None if e0 is None else _f64(e0).ravel()
-        _lib.check(_lib.lib().fep_step_kernel_time(self._h, stream, int(reps), u, _lib.ptr(e0v), ep or None, s or None,
-                                                   ds or None, ind_p or None, C.byref(ms)), 'fep_step_kernel_time')
-        return float(ms.value)
+    def profile_begin(self):
+        """Start bracketing every kernel of the following step_dev/assemble_dev calls with HIP events."""
+        _lib.check(_lib.lib().fep_ctx_profile_begin(self._h), 'fep_ctx_profile_begin')
+
+    def profile_end(self, stream):
+        """-> ({'element': ms, 'csr': ms, 'force': ms} average per launch, n_steps)."""
+        ms = (C.c_double * 3)()
+        n = C.c_int()
+        _lib.check(_lib.lib().fep_ctx_profile_end(self._h, stream, ms, C.byref(n)), 'fep_ctx_profile_end')
+        return {'element': ms[0], 'csr': ms[1], 'force': ms[2]}, n.value
 
 
 # ---------------------------------------------------------------------------------------

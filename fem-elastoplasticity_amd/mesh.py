@@ -34,8 +34,40 @@ def square_mesh(n_seg, element_type, size_xy=10):
     Returns the reference's mesh dict: 'coordinates' (2,n_n), 'elements' (n_p,n_e) int64
     0-based, 'surface', 'dirichlet_nodes' (2,n_n), 'Q' (2,n_n) bool.
     """
+    return rect_mesh(n_seg, n_seg, element_type, size_xy, size_xy)
+
+
+def rect_mesh(n_x, n_y, element_type, size_x=10, size_y=10):
+    """Same numbering on an n_x by n_y cell rectangle [0,size_x]x[0,size_y] (P1/Q1 only); used for
+    the multi-GPU strips of the benchmark.  Boundary masks follow DP:178-184 with the footing on the
+    top edge y == size_y and rollers on x == size_x."""
     t = _coerce(element_type)
-    N = int(n_seg)
+    if n_x == n_y and size_x == size_y:
+        return _square(int(n_x), t, size_x)
+    if t not in (LagrangeElementType.P1, LagrangeElementType.Q1):
+        raise ValueError('rectangles are generated for P1/Q1 only')
+    Mx, My = int(n_x) + 1, int(n_y) + 1
+    xs = np.linspace(0, size_x, Mx)
+    ys = np.linspace(0, size_y, My)
+    coord = np.array([np.tile(xs, My), np.repeat(ys, Mx)])
+    ci, cj = np.meshgrid(np.arange(int(n_x)), np.arange(int(n_y)), indexing='xy')
+    ci, cj = ci.ravel(), cj.ravel()
+    V1, V2, V3, V4 = ci + Mx * cj, ci + 1 + Mx * cj, ci + 1 + Mx * (cj + 1), ci + Mx * (cj + 1)
+    if t is LagrangeElementType.P1:
+        elem = np.array((V1, V2, V4, V2, V3, V4)).reshape((3, 2 * ci.size), order='F')
+    else:
+        elem = np.array((V1, V2, V3, V4))
+    footing = np.logical_and(coord[1, :] == size_y, coord[0, :] <= 1.0001)
+    dirichlet = np.zeros(coord.shape)
+    dirichlet[1, footing] = 1
+    Q = coord > 0
+    Q[1, footing] = 0
+    Q[0, coord[0, :] == size_x] = 0
+    return {'coordinates': coord, 'elements': elem.astype(np.int64), 'surface': None,
+            'dirichlet_nodes': dirichlet, 'Q': Q}
+
+
+def _square(N, t, size_xy):
     ci, cj = np.meshgrid(np.arange(N), np.arange(N), indexing='xy')    # cell (i,j), j outer
     ci = ci.ravel()
     cj = cj.ravel()

@@ -160,16 +160,14 @@ int fep_assemble_dev(fep_ctx* ctx, void* stream, const double* ds_d, const doubl
 int fep_assemble_host(fep_ctx* ctx, const double* ds_h, const double* s_h,
                       double* k_data_h, double* f_out_h);
 
-/* Kernel-only timing hook used by bench.py: average milliseconds per launch of the dominant kernel
- * of the last fep_step_dev call sequence is measured by the caller with HIP events on `stream`;
- * this returns the names of the kernels a step launches (NUL-separated list, double-NUL terminated). */
-const char* fep_step_kernel_names(const fep_ctx* ctx);
-
-/* Timed replay for bench.py: enqueue `reps` launches of ONLY the dominant (fused element) kernel of
- * a step between two HIP events on `stream` and return the average ms per launch in *ms_out.
- * Inputs/outputs as fep_step_dev (same buffers are rewritten each launch). */
-int fep_step_kernel_time(fep_ctx* ctx, void* stream, int reps, const double* u_d, const double* e0_h,
-                         double* ep_prev_d, double* s_d, double* ds_d, uint8_t* ind_p_d, float* ms_out);
+/* ---- in-situ kernel timing (bench.py's roofline figure) --------------------------------
+ * Between fep_ctx_profile_begin and fep_ctx_profile_end every fep_step_dev / fep_assemble_dev call
+ * brackets each of its kernels with HIP events on the launch stream (the kernels run in their real
+ * position inside the step, not replayed back to back).  _end synchronises the stream and returns
+ * the average milliseconds per launch: ms_out[0] fused element kernel (strain + return map + K_e,
+ * f_e), ms_out[1] CSR numeric phase, ms_out[2] force gather; *n_steps = steps averaged. */
+int fep_ctx_profile_begin(fep_ctx* ctx);
+int fep_ctx_profile_end(fep_ctx* ctx, void* stream, double ms_out[3], int* n_steps);
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,19 @@ def test_elastic_setup_vs_reference_golden(fep, t):
 
 
 # ---- a1..a5 ---------------------------------------------------------------------------
+@pytest.fixture(params=['node', 'node_direct', 'coo'])
+def p1_route(request, monkeypatch):
+    """P1 has two routes: the node-centric fast path (default) and the generic COO route."""
+    monkeypatch.setenv('FEP_P1_PATH', request.param)
+    return request.param
+
+
+def test_p1_routes_agree_and_match_reference(fep, p1_route):
+    test_hot_path_vs_reference_golden(fep, 'P1', True)
+    test_hot_path_vs_reference_golden(fep, 'P1', False)
+    test_hot_path_mid_size_vs_oracle(fep, 'P1', 60)
+
+
 @pytest.mark.parametrize('t', ELS)
 @pytest.mark.parametrize('accept', [False, True])
 def test_hot_path_vs_reference_golden(fep, t, accept):
