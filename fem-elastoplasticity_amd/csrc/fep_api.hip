@@ -48,7 +48,14 @@ struct fep_ctx {
     int32_t *perm2 = nullptr, *ncol = nullptr;
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
-    int lds_L = 0;
+    // persistent pipelined variant: per-tile tables padded to fixed strides
+    bool p1_pipe = false;
+    int pipe_cw = 0;                                    // 32-bit words of gather codes per lane and tile (1 or 2)
+    int32_t *elist_pad = nullptr, *fnode_pad = nullptr;
+    int32_t* pos_pad = nullptr;
+    uint32_t *seg_pad = nullptr, *deg_pad = nullptr;
+    uint32_t* codes_pad = nullptr;                      // 2 uint16 codes per word
+    int lds_L = 0, lds_C = 0;                           // staged elements / gather codes per workgroup (max)
     // device, scratch rewritten by every step
     double *Kc = nullptr, *fe = nullptr;
     double *s_int = nullptr, *ds_int = nullptr;     // used when the caller does not ask for s / ds
@@ -357,7 +364,8 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
-                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->perm_l};
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->perm_l,
+                        c->elist_pad, c->fnode_pad, c->seg_pad, c->deg_pad, c->pos_pad, c->codes_pad};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -450,16 +458,62 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                     }
                 });
             for (auto& t : th) t.join();
-            size_t lmax = 0;
-            for (int64_t g = 0; g < n_wg; ++g) { eptr[g + 1] = eptr[g] + (int32_t)lists[g].size(); lmax = std::max(lmax, lists[g].size()); }
+            size_t lmax = 0, cmax = 0;
+            for (int64_t g = 0; g < n_wg; ++g) {
+                eptr[g + 1] = eptr[g] + (int32_t)lists[g].size();
+                lmax = std::max(lmax, lists[g].size());
+                const int64_t b0 = g * kBlock, b1 = std::min<int64_t>(c->n_blk, b0 + kBlock);
+                cmax = std::max(cmax, (size_t)(S.segptr[b1] - S.segptr[b0]));
+            }
+            c->lds_C = (int)((cmax + 7) & ~(size_t)7);
             std::vector<int32_t> elist((size_t)eptr[n_wg]);
             for (int64_t g = 0; g < n_wg; ++g) std::copy(lists[g].begin(), lists[g].end(), elist.begin() + eptr[g]);
             const char* pth = std::getenv("FEP_P1_PATH");
             c->lds_L = (int)((lmax + 1) & ~(size_t)1);
             // 15 doubles per staged element; fall back to the direct-gather kernel when a list would not fit
-            c->p1_lds = lmax < 4096 && (size_t)c->lds_L * 15 * sizeof(double) <= 96 * 1024 &&
+            c->p1_lds = lmax < 4096 && (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 <= 96 * 1024 &&
                         !(pth && std::strcmp(pth, "node_direct") == 0);
-            if (c->p1_lds) {
+            const int cw = (int)((cmax + 2 * kBlock - 1) / (2 * kBlock));
+            // persistent pipelined variant: opt-in (FEP_P1_PATH=node_pipe); measured no faster than the staged kernel
+            c->p1_pipe = c->p1_lds && lmax <= (size_t)kBlock && cw <= 2 && pth && std::strcmp(pth, "node_pipe") == 0;
+            if (c->p1_pipe) {
+                c->pipe_cw = cw < 1 ? 1 : cw;
+                const int CPT = 2 * c->pipe_cw;
+                std::vector<int32_t> elist_pad((size_t)n_wg * kBlock, 0), fnode_pad((size_t)n_wg * kBlock, -1);
+                std::vector<int32_t> pos_pad((size_t)n_wg * kBlock, -1);
+                std::vector<uint32_t> seg_pad((size_t)n_wg * kBlock, 0u), deg_pad((size_t)n_wg * kBlock, 0u);
+                std::vector<uint16_t> codes_pad((size_t)n_wg * CPT * kBlock, 0);
+                std::vector<int> order(kBlock);
+                for (int64_t g = 0; g < n_wg; ++g) {
+                    // unused lanes stage the tile's first element again (a valid, local address: no branch)
+                    std::fill(elist_pad.begin() + g * kBlock, elist_pad.begin() + (g + 1) * kBlock, lists[g].empty() ? 0 : lists[g][0]);
+                    std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * kBlock);
+                    const int64_t b0 = g * kBlock, b1 = std::min<int64_t>(c->n_blk, b0 + kBlock);
+                    const int32_t t0 = S.segptr[b0];
+                    // lanes sorted by descending segment length (stable): equal trip counts inside a wave
+                    const int nb = (int)(b1 - b0);
+                    for (int k = 0; k < nb; ++k) order[k] = k;
+                    std::stable_sort(order.begin(), order.begin() + nb, [&](int x, int y) {
+                        return S.segptr[b0 + x + 1] - S.segptr[b0 + x] > S.segptr[b0 + y + 1] - S.segptr[b0 + y];
+                    });
+                    for (int k = 0; k < nb; ++k) {
+                        const int64_t b = b0 + order[k], o = b0 + k;
+                        const uint32_t mt = S.meta[b];
+                        seg_pad[o] = ((uint32_t)(S.segptr[b] - t0) << 16) | (uint32_t)(S.segptr[b + 1] - t0);
+                        pos_pad[o] = (int32_t)(4 * b - 2 * (int64_t)(mt & 0x7fffu));
+                        deg_pad[o] = mt >> 16;
+                        if (mt & 0x8000u) fnode_pad[o] = S.ncol[b];
+                    }
+                    // code k of the tile sits at uint16 index g*CPT*256 + k (word r*256+lane holds codes 2(r*256+lane), +1)
+                    std::copy(perm_l.begin() + t0, perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * CPT * kBlock);
+                }
+                CK(upload(&c->elist_pad, elist_pad.data(), (int64_t)elist_pad.size()));
+                CK(upload(&c->fnode_pad, fnode_pad.data(), (int64_t)fnode_pad.size()));
+                CK(upload(&c->seg_pad, seg_pad.data(), (int64_t)seg_pad.size()));
+                CK(upload(&c->pos_pad, pos_pad.data(), (int64_t)pos_pad.size()));
+                CK(upload(&c->deg_pad, deg_pad.data(), (int64_t)deg_pad.size()));
+                CK(upload(&c->codes_pad, reinterpret_cast<const uint32_t*>(codes_pad.data()), (int64_t)codes_pad.size() / 2));
+            } else if (c->p1_lds) {
                 CK(upload(&c->wg_eptr, eptr.data(), (int64_t)eptr.size()));
                 CK(upload(&c->wg_elist, elist.data(), (int64_t)elist.size()));
                 CK(upload(&c->perm_l, perm_l.data(), (int64_t)perm_l.size()));
@@ -582,7 +636,7 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
 
 static int launch_counts(fep_ctx* c, hipStream_t st, unsigned long long* counts_d) {
     if (!counts_d) return FEP_OK;
-    hipLaunchKernelGGL(counts_reduce_kernel, dim3(1), dim3(kBlock), 0, st, c->n_count_blocks, c->blk_counts, counts_d);
+    hipLaunchKernelGGL(counts_reduce_kernel, dim3(1), dim3(1024), 0, st, c->n_count_blocks, c->blk_counts, counts_d);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }
@@ -606,16 +660,59 @@ static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_o
 }
 
 // P1 node route, assembly kernel (reads ds / s, writes CSR values and nodal force)
-static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const double* s, double* k_data, double* f_out) {
+// `counts_d` != NULL: the assembly kernel also sums the point kernel's per-workgroup branch counters
+// (*counts_done tells the caller whether that happened)
+static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const double* s, double* k_data, double* f_out,
+                          unsigned long long* counts_d, bool* counts_done) {
     FEP_TRY(prof_mark(c, st));
+    if (counts_done) *counts_done = false;
     if ((k_data && ds) || (f_out && s)) {
-        if (c->p1_lds) {
-            const size_t lds = (size_t)c->lds_L * 15 * sizeof(double);
+        if (c->p1_pipe) {
+            const int n_tiles = (int)grid_for(c->n_blk, kBlock);
+            const int chunk = (n_tiles + 7) / 8;
+            static const int kWgsPerXcd = []() { const char* v = std::getenv("FEP_PIPE_WGS"); return v ? std::atoi(v) : 128; }();
+            const int W = chunk < kWgsPerXcd ? chunk : kWgsPerXcd;      // workgroups per XCD (32 CUs x 4)
+            const double* dsp = k_data ? ds : nullptr;
+            const double* sp = f_out ? s : nullptr;
+#define PIPE(CW, HD, HS)                                                                                           \
+    hipLaunchKernelGGL((p1_node_pipe_kernel<CW, HD, HS>), dim3(8 * W), dim3(kBlock), 0, st, c->n_e, n_tiles,          \
+                       c->elist_pad, c->seg_pad, c->pos_pad, c->deg_pad, c->fnode_pad, c->codes_pad, c->geo, dsp, sp, \
+                       k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d)
+            static const int kDbg = []() { const char* v = std::getenv("FEP_PIPE_DBG"); return v ? std::atoi(v) : 0; }();
+            const int sel = kDbg ? 100 + kDbg : (c->pipe_cw == 1 ? 0 : 4) + (dsp ? 2 : 0) + (sp ? 1 : 0);
+#define PIPED(D)                                                                                                     \
+    hipLaunchKernelGGL((p1_node_pipe_kernel<2, true, true, D>), dim3(8 * W), dim3(kBlock), 0, st, c->n_e, n_tiles,    \
+                       c->elist_pad, c->seg_pad, c->pos_pad, c->deg_pad, c->fnode_pad, c->codes_pad, c->geo, dsp, sp, \
+                       k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d)
+            switch (sel) {
+                case 101: PIPED(1); break;
+                case 102: PIPED(2); break;
+                case 103: PIPED(3); break;
+                case 104: PIPED(4); break;
+                case 105: PIPED(5); break;
+                case 106: PIPED(6); break;
+                case 107: PIPED(7); break;
+                case 1: PIPE(1, false, true); break;
+                case 2: PIPE(1, true, false); break;
+                case 3: PIPE(1, true, true); break;
+                case 5: PIPE(2, false, true); break;
+                case 6: PIPE(2, true, false); break;
+                case 7: PIPE(2, true, true); break;
+                default: return FEP_EINVAL;
+            }
+#undef PIPE
+            if (counts_done) *counts_done = counts_d != nullptr;
+        } else if (c->p1_lds) {
+            const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
             if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(p1_node_lds_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), lds, st,
+                HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int n_wg = (int)grid_for(c->n_blk, kBlock);
+            const int chunk = (n_wg + 7) / 8;
+            hipLaunchKernelGGL(p1_node_lds_kernel<false>, dim3(8 * chunk), dim3(kBlock), lds, st,
                                c->n_blk, c->n_e, c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist,
-                               c->geo, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out);
+                               c->geo, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out,
+                               n_wg, c->n_count_blocks, c->blk_counts, counts_d, (long long*)nullptr);
+            if (counts_done) *counts_done = counts_d != nullptr;
         } else {
             hipLaunchKernelGGL(p1_node_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
                                c->n_blk, c->n_e, c->segptr, c->perm2, c->meta, c->ncol, c->geo,
@@ -653,8 +750,9 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
                            c->n_e, c->elem, c->geo, u_d, e0, ep_prev_d, c->shear, c->bulk, c->eta, c->c, accept,
                            e_out_d, s_d, ds_d, ind_p_d, blk);
         HIP_TRY(hipGetLastError());
-        FEP_TRY(launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d));
-        return launch_counts(c, st, cnt);
+        bool counted = false;
+        FEP_TRY(launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, cnt, &counted));
+        return counted ? FEP_OK : launch_counts(c, st, cnt);
     }
     FEP_TRY(prof_mark(c, st));
 #define CALL(NP, NQ)                                                                                     \
@@ -674,7 +772,7 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
     hipStream_t st = (hipStream_t)stream;
     if (c->p1_node) {
         FEP_TRY(prof_mark(c, st));
-        return launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d);
+        return launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, nullptr, nullptr);
     }
     const E0 e0 = make_e0(nullptr);
     FEP_TRY(prof_mark(c, st));
@@ -761,4 +859,29 @@ extern "C" int fep_ctx_profile_end(fep_ctx* c, void* stream, double ms_out[3], i
     for (int k = 0; k < 3; ++k) ms_out[k] = n ? acc[k] / n : 0.0;
     if (n_steps) *n_steps = n;
     return FEP_OK;
+}
+
+// Diagnostic (not part of include/fep.h's product surface; used by tools/node_stamps.py): one launch of the
+// stamped build of the P1 assembly kernel; stamps_h receives n_wg x 8 int64 (s_memtime at phase
+// boundaries, blockIdx, staged element count).  Returns the number of workgroups in *n_wg_out.
+extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const double* s_d, double* k_data_d,
+                                        double* f_out_d, long long* stamps_h, int64_t cap, int* n_wg_out) {
+    if (!c || !c->p1_node || !c->p1_lds || !ds_d || !s_d || !k_data_d || !f_out_d || !stamps_h) return FEP_EINVAL;
+    FEP_TRY(set_device(c->device));
+    const int n_wg = (int)grid_for(c->n_blk, kBlock);
+    if (n_wg_out) *n_wg_out = n_wg;
+    if (cap < (int64_t)n_wg * 8) return FEP_EINVAL;
+    DevBuf st;
+    FEP_TRY(st.alloc((int64_t)n_wg * 8 * sizeof(long long)));
+    const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
+    const int chunk = (n_wg + 7) / 8;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(p1_node_lds_kernel<true>, dim3(8 * chunk), dim3(kBlock), lds, nullptr,
+                           c->n_blk, c->n_e, c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist,
+                           c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0, (const uint2*)nullptr,
+                           (unsigned long long*)nullptr, st.as<long long>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return st.to(stamps_h, (int64_t)n_wg * 8 * sizeof(long long));
 }
