@@ -21,10 +21,12 @@ from .hotpath import (MeshContext, assemble_tangent, construct_constitutive_prob
 from ._lib import FepError, lib, lib_path
 from .build import build
 from .sharding import Partition, ShardedContext, element_ranges
+from .newton import solve_strip_footing, solve_tsx_tunnel, transform
 from . import plasticity2d_dp, tsx_tunnel, elasticity2d
 
 __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get_local_basis_volume',
            'element_tables', 'assemble_mesh', 'square_mesh', 'rect_mesh', 'Partition', 'ShardedContext', 'element_ranges', 'MeshContext', 'construct_constitutive_problem',
            'construct_constitutive_problem_tsx', 'get_elastic_stiffness_matrix', 'get_elastic_stiffness_matrix_el',
            'assemble_tangent', 'default_device', 'FepError', 'lib', 'lib_path', 'build',
+           'solve_strip_footing', 'solve_tsx_tunnel', 'transform',
            'plasticity2d_dp', 'tsx_tunnel', 'elasticity2d']

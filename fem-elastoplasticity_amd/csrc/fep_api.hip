@@ -44,17 +44,12 @@ struct fep_ctx {
     uint32_t* meta = nullptr;
     // P1 fast path (node-centric gather assembly): 64-byte geometry records, re-encoded gather list
     bool p1_node = false, p1_lds = false;
-    double* geo = nullptr;
+    double *geo = nullptr, *xy = nullptr;               // xy: interleaved (x,y) per node
+    P1Tab p1tab{};
     int32_t *perm2 = nullptr, *ncol = nullptr;
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
-    // persistent pipelined variant: per-tile tables padded to fixed strides
-    bool p1_pipe = false;
-    int pipe_cw = 0;                                    // 32-bit words of gather codes per lane and tile (1 or 2)
-    int32_t *elist_pad = nullptr, *fnode_pad = nullptr;
-    int32_t* pos_pad = nullptr;
-    uint32_t *seg_pad = nullptr, *deg_pad = nullptr;
-    uint32_t* codes_pad = nullptr;                      // 2 uint16 codes per word
+    int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
     int lds_L = 0, lds_C = 0;                           // staged elements / gather codes per workgroup (max)
     // device, scratch rewritten by every step
     double *Kc = nullptr, *fe = nullptr;
@@ -364,8 +359,7 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
-                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->perm_l,
-                        c->elist_pad, c->fnode_pad, c->seg_pad, c->deg_pad, c->pos_pad, c->codes_pad};
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->perm_l, c->xy};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -434,8 +428,10 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         }
         CK(upload(&c->perm2, perm2.data(), (int64_t)perm2.size()));
         CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
-        {   // per-workgroup (256 consecutive blocks) sorted unique element lists + local gather codes
-            const int64_t n_wg = (c->n_blk + kBlock - 1) / kBlock;
+        {   // per-workgroup (`tile` consecutive blocks) sorted unique element lists + local gather codes
+            if (const char* tv = std::getenv("FEP_NODE_TILE")) { const int t = std::atoi(tv); if (t == 128 || t == 256 || t == 512) c->tile = t; }
+            const int64_t TILE = c->tile;
+            const int64_t n_wg = (c->n_blk + TILE - 1) / TILE;
             std::vector<int32_t> eptr(n_wg + 1, 0);
             std::vector<std::vector<int32_t>> lists(n_wg);
             std::vector<uint16_t> perm_l(perm2.size());
@@ -444,7 +440,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             for (int w = 0; w < nthreads; ++w)
                 th.emplace_back([&, w]() {
                     for (int64_t g = n_wg * w / nthreads; g < n_wg * (w + 1) / nthreads; ++g) {
-                        const int64_t b0 = g * kBlock, b1 = std::min<int64_t>(c->n_blk, b0 + kBlock);
+                        const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
                         const int32_t t0 = S.segptr[b0], t1 = S.segptr[b1];
                         std::vector<int32_t>& l = lists[g];
                         l.reserve(t1 - t0);
@@ -462,7 +458,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             for (int64_t g = 0; g < n_wg; ++g) {
                 eptr[g + 1] = eptr[g] + (int32_t)lists[g].size();
                 lmax = std::max(lmax, lists[g].size());
-                const int64_t b0 = g * kBlock, b1 = std::min<int64_t>(c->n_blk, b0 + kBlock);
+                const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
                 cmax = std::max(cmax, (size_t)(S.segptr[b1] - S.segptr[b0]));
             }
             c->lds_C = (int)((cmax + 7) & ~(size_t)7);
@@ -473,53 +469,20 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             // 15 doubles per staged element; fall back to the direct-gather kernel when a list would not fit
             c->p1_lds = lmax < 4096 && (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 <= 96 * 1024 &&
                         !(pth && std::strcmp(pth, "node_direct") == 0);
-            const int cw = (int)((cmax + 2 * kBlock - 1) / (2 * kBlock));
-            // persistent pipelined variant: opt-in (FEP_P1_PATH=node_pipe); measured no faster than the staged kernel
-            c->p1_pipe = c->p1_lds && lmax <= (size_t)kBlock && cw <= 2 && pth && std::strcmp(pth, "node_pipe") == 0;
-            if (c->p1_pipe) {
-                c->pipe_cw = cw < 1 ? 1 : cw;
-                const int CPT = 2 * c->pipe_cw;
-                std::vector<int32_t> elist_pad((size_t)n_wg * kBlock, 0), fnode_pad((size_t)n_wg * kBlock, -1);
-                std::vector<int32_t> pos_pad((size_t)n_wg * kBlock, -1);
-                std::vector<uint32_t> seg_pad((size_t)n_wg * kBlock, 0u), deg_pad((size_t)n_wg * kBlock, 0u);
-                std::vector<uint16_t> codes_pad((size_t)n_wg * CPT * kBlock, 0);
-                std::vector<int> order(kBlock);
-                for (int64_t g = 0; g < n_wg; ++g) {
-                    // unused lanes stage the tile's first element again (a valid, local address: no branch)
-                    std::fill(elist_pad.begin() + g * kBlock, elist_pad.begin() + (g + 1) * kBlock, lists[g].empty() ? 0 : lists[g][0]);
-                    std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * kBlock);
-                    const int64_t b0 = g * kBlock, b1 = std::min<int64_t>(c->n_blk, b0 + kBlock);
-                    const int32_t t0 = S.segptr[b0];
-                    // lanes sorted by descending segment length (stable): equal trip counts inside a wave
-                    const int nb = (int)(b1 - b0);
-                    for (int k = 0; k < nb; ++k) order[k] = k;
-                    std::stable_sort(order.begin(), order.begin() + nb, [&](int x, int y) {
-                        return S.segptr[b0 + x + 1] - S.segptr[b0 + x] > S.segptr[b0 + y + 1] - S.segptr[b0 + y];
-                    });
-                    for (int k = 0; k < nb; ++k) {
-                        const int64_t b = b0 + order[k], o = b0 + k;
-                        const uint32_t mt = S.meta[b];
-                        seg_pad[o] = ((uint32_t)(S.segptr[b] - t0) << 16) | (uint32_t)(S.segptr[b + 1] - t0);
-                        pos_pad[o] = (int32_t)(4 * b - 2 * (int64_t)(mt & 0x7fffu));
-                        deg_pad[o] = mt >> 16;
-                        if (mt & 0x8000u) fnode_pad[o] = S.ncol[b];
-                    }
-                    // code k of the tile sits at uint16 index g*CPT*256 + k (word r*256+lane holds codes 2(r*256+lane), +1)
-                    std::copy(perm_l.begin() + t0, perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * CPT * kBlock);
-                }
-                CK(upload(&c->elist_pad, elist_pad.data(), (int64_t)elist_pad.size()));
-                CK(upload(&c->fnode_pad, fnode_pad.data(), (int64_t)fnode_pad.size()));
-                CK(upload(&c->seg_pad, seg_pad.data(), (int64_t)seg_pad.size()));
-                CK(upload(&c->pos_pad, pos_pad.data(), (int64_t)pos_pad.size()));
-                CK(upload(&c->deg_pad, deg_pad.data(), (int64_t)deg_pad.size()));
-                CK(upload(&c->codes_pad, reinterpret_cast<const uint32_t*>(codes_pad.data()), (int64_t)codes_pad.size() / 2));
-            } else if (c->p1_lds) {
+            if (c->p1_lds) {
                 CK(upload(&c->wg_eptr, eptr.data(), (int64_t)eptr.size()));
                 CK(upload(&c->wg_elist, elist.data(), (int64_t)elist.size()));
                 CK(upload(&c->perm_l, perm_l.data(), (int64_t)perm_l.size()));
             }
         }
         CK(dmalloc(&c->geo, 8 * n_e));
+        {
+            std::vector<double> xy(2 * (size_t)n_n);
+            for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
+            CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
+            for (int a = 0; a < 3; ++a) { c->p1tab.h1[a] = dhatp1_h[a]; c->p1tab.h2[a] = dhatp2_h[a]; }
+            c->p1tab.wf = wf_h[0];
+        }
         c->n_count_blocks = (int)grid_for(n_e, kBlock);
     } else {
         CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
@@ -667,51 +630,22 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
     FEP_TRY(prof_mark(c, st));
     if (counts_done) *counts_done = false;
     if ((k_data && ds) || (f_out && s)) {
-        if (c->p1_pipe) {
-            const int n_tiles = (int)grid_for(c->n_blk, kBlock);
-            const int chunk = (n_tiles + 7) / 8;
-            static const int kWgsPerXcd = []() { const char* v = std::getenv("FEP_PIPE_WGS"); return v ? std::atoi(v) : 128; }();
-            const int W = chunk < kWgsPerXcd ? chunk : kWgsPerXcd;      // workgroups per XCD (32 CUs x 4)
-            const double* dsp = k_data ? ds : nullptr;
-            const double* sp = f_out ? s : nullptr;
-#define PIPE(CW, HD, HS)                                                                                           \
-    hipLaunchKernelGGL((p1_node_pipe_kernel<CW, HD, HS>), dim3(8 * W), dim3(kBlock), 0, st, c->n_e, n_tiles,          \
-                       c->elist_pad, c->seg_pad, c->pos_pad, c->deg_pad, c->fnode_pad, c->codes_pad, c->geo, dsp, sp, \
-                       k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d)
-            static const int kDbg = []() { const char* v = std::getenv("FEP_PIPE_DBG"); return v ? std::atoi(v) : 0; }();
-            const int sel = kDbg ? 100 + kDbg : (c->pipe_cw == 1 ? 0 : 4) + (dsp ? 2 : 0) + (sp ? 1 : 0);
-#define PIPED(D)                                                                                                     \
-    hipLaunchKernelGGL((p1_node_pipe_kernel<2, true, true, D>), dim3(8 * W), dim3(kBlock), 0, st, c->n_e, n_tiles,    \
-                       c->elist_pad, c->seg_pad, c->pos_pad, c->deg_pad, c->fnode_pad, c->codes_pad, c->geo, dsp, sp, \
-                       k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d)
-            switch (sel) {
-                case 101: PIPED(1); break;
-                case 102: PIPED(2); break;
-                case 103: PIPED(3); break;
-                case 104: PIPED(4); break;
-                case 105: PIPED(5); break;
-                case 106: PIPED(6); break;
-                case 107: PIPED(7); break;
-                case 1: PIPE(1, false, true); break;
-                case 2: PIPE(1, true, false); break;
-                case 3: PIPE(1, true, true); break;
-                case 5: PIPE(2, false, true); break;
-                case 6: PIPE(2, true, false); break;
-                case 7: PIPE(2, true, true); break;
-                default: return FEP_EINVAL;
-            }
-#undef PIPE
-            if (counts_done) *counts_done = counts_d != nullptr;
-        } else if (c->p1_lds) {
+        if (c->p1_lds) {
             const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
-            if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int n_wg = (int)grid_for(c->n_blk, kBlock);
+            const int n_wg = (int)grid_for(c->n_blk, c->tile);
             const int chunk = (n_wg + 7) / 8;
-            hipLaunchKernelGGL(p1_node_lds_kernel<false>, dim3(8 * chunk), dim3(kBlock), lds, st,
-                               c->n_blk, c->n_e, c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist,
-                               c->geo, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out,
-                               n_wg, c->n_count_blocks, c->blk_counts, counts_d, (long long*)nullptr);
+#define NODE_LDS(TPB)                                                                                                    \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB>,                                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+        hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB>), dim3(8 * chunk), dim3(TPB), lds, st, c->n_blk, c->n_e,      \
+                           c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist, c->geo,            \
+                           k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks,           \
+                           c->blk_counts, counts_d, (long long*)nullptr);                                               \
+    } while (0)
+            if (c->tile == 128) NODE_LDS(128); else if (c->tile == 512) NODE_LDS(512); else NODE_LDS(256);
+#undef NODE_LDS
             if (counts_done) *counts_done = counts_d != nullptr;
         } else {
             hipLaunchKernelGGL(p1_node_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
@@ -747,7 +681,7 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
         }
         FEP_TRY(prof_mark(c, st));
         hipLaunchKernelGGL(p1_point_kernel, dim3(grid_for(c->n_e, kBlock)), dim3(kBlock), 0, st,
-                           c->n_e, c->elem, c->geo, u_d, e0, ep_prev_d, c->shear, c->bulk, c->eta, c->c, accept,
+                           c->n_e, c->elem, c->xy, c->p1tab, u_d, e0, ep_prev_d, c->shear, c->bulk, c->eta, c->c, accept,
                            e_out_d, s_d, ds_d, ind_p_d, blk);
         HIP_TRY(hipGetLastError());
         bool counted = false;
@@ -868,6 +802,7 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
                                         double* f_out_d, long long* stamps_h, int64_t cap, int* n_wg_out) {
     if (!c || !c->p1_node || !c->p1_lds || !ds_d || !s_d || !k_data_d || !f_out_d || !stamps_h) return FEP_EINVAL;
     FEP_TRY(set_device(c->device));
+    if (c->tile != 256) return FEP_EINVAL;
     const int n_wg = (int)grid_for(c->n_blk, kBlock);
     if (n_wg_out) *n_wg_out = n_wg;
     if (cap < (int64_t)n_wg * 8) return FEP_EINVAL;
@@ -876,7 +811,7 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
     const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
     const int chunk = (n_wg + 7) / 8;
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL(p1_node_lds_kernel<true>, dim3(8 * chunk), dim3(kBlock), lds, nullptr,
+        hipLaunchKernelGGL((p1_node_lds_kernel<true, 256>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
                            c->n_blk, c->n_e, c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist,
                            c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0, (const uint2*)nullptr,
                            (unsigned long long*)nullptr, st.as<long long>());

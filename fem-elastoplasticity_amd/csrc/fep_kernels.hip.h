@@ -407,10 +407,36 @@ force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t
     *reinterpret_cast<double2*>(F + 2 * n) = make_double2(f0, f1);
 }
 
+// P1 geometry recomputed from the node coordinates (48 bytes gathered through L2 instead of a 64-byte
+// record streamed from HBM).  Same operations, same order, no FMA contraction as geometry_kernel, hence
+// bit-identical dphi / weight (DP:530-546, 585).  `tab` = the P1 reference-element tables.
+struct P1Tab { double h1[3], h2[3], wf; };
+
+__device__ __forceinline__ void p1_geometry(const P1Tab& tab, const double2 c0, const double2 c1, const double2 c2,
+                                            double d1[3], double d2[3], double& w) {
+#pragma clang fp contract(off)
+    const double x[3] = {c0.x, c1.x, c2.x}, y[3] = {c0.y, c1.y, c2.y};
+    double j11 = 0.0, j12 = 0.0, j21 = 0.0, j22 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        j11 = j11 + x[a] * tab.h1[a]; j12 = j12 + y[a] * tab.h1[a];
+        j21 = j21 + x[a] * tab.h2[a]; j22 = j22 + y[a] * tab.h2[a];
+    }
+    const double det = j11 * j22 - j12 * j21;
+    const double i11 = j22 / det, i12 = -j12 / det, i21 = -j21 / det, i22 = j11 / det;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d1[a] = i11 * tab.h1[a] + i12 * tab.h2[a];
+        d2[a] = i21 * tab.h1[a] + i22 * tab.h2[a];
+    }
+    w = fabs(det) * tab.wf;
+}
+
 // ---------------------------------------------------------------------------------------
 // P1 fast path (3-node triangle, 1 integration point): no element-matrix round trip through HBM.
 //
-//   p1_point_kernel   one lane per element: strain from U (a1) + return map (a2); writes s, ds, ind_p.
+//   p1_point_kernel   one lane per element: geometry from the coordinates, strain from U (a1), return map (a2);
+//                     writes s, ds, ind_p.
 //   p1_node_kernel    one lane per node-pair block of the CSR pattern: gathers, for every element that
 //                     contributes to the block, its tangent (6 values of ds), weight and the two nodes'
 //                     dphi, forms the 2x2 block  w * B_a^T DS B_b  on the fly and sums in the fixed
@@ -421,7 +447,7 @@ force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t
 //   perm2[t] = e*16 + a*4 + b ;  meta = (deg << 16) | (diag << 15) | slot
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-p1_point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __restrict__ geo,
+p1_point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __restrict__ xy, P1Tab tab,
                 const double* __restrict__ U, E0 e0, double* __restrict__ ep,
                 const double* __restrict__ shear, const double* __restrict__ bulk,
                 const double* __restrict__ eta, const double* __restrict__ cc, int accept,
@@ -431,15 +457,18 @@ p1_point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __r
     int branch = 0;
     if (e < n_e) {
         const int64_t n0 = elem[e], n1 = elem[n_e + e], n2 = elem[2 * n_e + e];
-        const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
-        const double2 g0 = g[0], g1 = g[1], g2 = g[2];          // (d1_0,d1_1) (d1_2,d2_0) (d2_1,d2_2)
+        const double2 c0 = *reinterpret_cast<const double2*>(xy + 2 * n0);
+        const double2 c1 = *reinterpret_cast<const double2*>(xy + 2 * n1);
+        const double2 c2 = *reinterpret_cast<const double2*>(xy + 2 * n2);
         const double2 u0 = *reinterpret_cast<const double2*>(U + 2 * n0);
         const double2 u1 = *reinterpret_cast<const double2*>(U + 2 * n1);
         const double2 u2 = *reinterpret_cast<const double2*>(U + 2 * n2);
+        double d1[3], d2[3], w;
+        p1_geometry(tab, c0, c1, c2, d1, d2, w);
         double ev[3];                                            // DP:1043, local node order
-        ev[0] = g0.x * u0.x + g0.y * u1.x + g1.x * u2.x;
-        ev[1] = g1.y * u0.y + g2.x * u1.y + g2.y * u2.y;
-        ev[2] = (g1.y * u0.x + g0.x * u0.y) + (g2.x * u1.x + g0.y * u1.y) + (g2.y * u2.x + g1.x * u2.y);
+        ev[0] = d1[0] * u0.x + d1[1] * u1.x + d1[2] * u2.x;
+        ev[1] = d2[0] * u0.y + d2[1] * u1.y + d2[2] * u2.y;
+        ev[2] = (d2[0] * u0.x + d1[0] * u0.y) + (d2[1] * u1.x + d1[1] * u1.y) + (d2[2] * u2.x + d1[2] * u2.y);
         double p[4] = {0.0, 0.0, 0.0, 0.0};
         if (ep) { p[0] = ep[e]; p[1] = ep[n_e + e]; p[2] = ep[2 * n_e + e]; p[3] = ep[3 * n_e + e]; }
         double s[4], d[6];
@@ -506,8 +535,8 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 //   perm_l[t] = (local element index << 4) | a << 2 | b      (uint16)
 //   LDS: rec[15][L] doubles, L = max list length, then the workgroup's gather codes (uint16)
 // ---------------------------------------------------------------------------------------
-template <bool DIAG>
-__global__ void __launch_bounds__(kBlock)
+template <bool DIAG, int TPB>
+__global__ void __launch_bounds__(TPB)
 p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict__ segptr,
                    const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
                    const int32_t* __restrict__ ncol, const int32_t* __restrict__ wg_eptr,
@@ -530,18 +559,18 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict_
     if (wg >= n_wg) return;
     // everything that does not depend on the staged data is requested up front: the lane's own segment
     // bounds / meta word, and the workgroup's contiguous range of gather codes (into LDS)
-    const int64_t sb = (int64_t)wg * kBlock + threadIdx.x;
+    const int64_t sb = (int64_t)wg * TPB + threadIdx.x;
     const bool live = sb < n_blk;
-    const int64_t sb_first = (int64_t)wg * kBlock;
-    const int64_t sb_last = sb_first + kBlock < n_blk ? sb_first + kBlock : n_blk;
+    const int64_t sb_first = (int64_t)wg * TPB;
+    const int64_t sb_last = sb_first + TPB < n_blk ? sb_first + TPB : n_blk;
     const int32_t t0 = segptr[sb_first], t1 = segptr[sb_last];
     const int32_t beg = live ? segptr[sb] : 0, end = live ? segptr[sb + 1] : 0;
     const uint32_t m = live ? meta[sb] : 0u;
     uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
-    for (int i = threadIdx.x; i < t1 - t0; i += kBlock) codes[i] = perm_l[t0 + i];
+    for (int i = threadIdx.x; i < t1 - t0; i += TPB) codes[i] = perm_l[t0 + i];
     if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st1 = (long long)__builtin_amdgcn_s_memtime(); }   // prologue loads landed
     const int ebeg = wg_eptr[wg], ecnt = wg_eptr[wg + 1] - ebeg;
-    for (int i = threadIdx.x; i < ecnt; i += kBlock) {
+    for (int i = threadIdx.x; i < ecnt; i += TPB) {
         const int64_t e = wg_elist[ebeg + i];
         if (DIAG && i == (int)threadIdx.x) { __builtin_amdgcn_s_waitcnt(0); st2 = (long long)__builtin_amdgcn_s_memtime(); }  // list entry landed
         const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
@@ -594,189 +623,6 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict_
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = (long long)__builtin_amdgcn_s_memtime();
         o[6] = blockIdx.x; o[7] = ecnt;
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of the LDS-staged assembly kernel (the default when every
-// workgroup tile touches <= 256 elements).  The staged kernel above is bound by latency: each tile
-// walks  list -> element data -> LDS -> barrier -> gather  with ~3 us per dependent memory step and
-// only 8 tiles resident per CU.  Here a workgroup walks many tiles and keeps the NEXT tile's operands
-// in flight (registers) while it gathers the CURRENT tile from LDS, and the element id of the tile
-// AFTER that, so no load inside the loop waits on another load of the same iteration.
-//
-// All per-tile tables are padded to fixed strides, so every address is a function of (tile, lane):
-//   elist_pad[tile*256 + lane]      element staged by this lane (-1 = none)
-//   seg_pad[tile*256 + lane]        (first code << 16) | (one past last code), tile-local
-//   meta_pad, fnode_pad[...]        meta word; node id if the block is a diagonal block else -1
-//   codes_pad[tile*CPT*256 + r*256 + lane]   gather codes (local element << 4 | a << 2 | b)
-// Tile order: XCD x (= blockIdx % 8) owns one contiguous eighth of the tiles and its workgroups take
-// them round-robin, so the tiles in flight on an XCD are neighbours and re-staged elements hit its L2.
-// ---------------------------------------------------------------------------------------
-struct P1Raw {               // operands of one element as loaded (scaled by w when written to LDS)
-    double2 g0, g1, g2, g3;
-    double d[6];
-    double s[3];
-};
-
-template <bool HAS_DS, bool HAS_S>
-__device__ __forceinline__ void p1_load_raw(P1Raw& r, int e, int64_t n_e, const double* __restrict__ geo,
-                                            const double* __restrict__ DS, const double* __restrict__ S) {
-    const double2* g = reinterpret_cast<const double2*>(geo + (int64_t)e * 8);
-    r.g0 = g[0]; r.g1 = g[1]; r.g2 = g[2]; r.g3 = g[3];
-    if (HAS_DS) {
-        r.d[0] = DS[e]; r.d[1] = DS[n_e + e]; r.d[2] = DS[2 * n_e + e];
-        r.d[3] = DS[4 * n_e + e]; r.d[4] = DS[5 * n_e + e]; r.d[5] = DS[8 * n_e + e];
-    }
-    if (HAS_S) { r.s[0] = S[e]; r.s[1] = S[n_e + e]; r.s[2] = S[2 * n_e + e]; }
-}
-
-// CW = 32-bit words of gather codes per lane and tile (2 codes per word).  The loop body contains no
-// branch around a load and consumes no loaded register before the next iteration's top, so the
-// compiler's only vmcnt wait sits there; the stores of a tile are issued one iteration late, BEFORE
-// the next prefetch, so that wait never covers a young store.
-//
-// LDS image of a tile: one 144-byte record per staged element (stride 18 doubles = 36 banks, so 16
-// consecutive records tile all 64 banks for ds_read_b128), laid out in 16-byte pairs
-//   [wD00 wD01][wD02 wD11][wD12 wD22][d1_0 d2_0][d1_1 d2_1][d1_2 d2_2][wS0 wS1][wS2 -]
-// => 5 ds_read_b128 per contribution (+2 on the lanes that own a diagonal block).
-// Lanes of a tile are sorted by descending segment length at setup (diagonal blocks, which sum one
-// contribution per incident element, sit together in the first wave), so a wave's trip count is
-// not set by a few long lanes.  pos_pad gives each lane the CSR position of its block (-1 = none).
-constexpr int kRecStride = 18;
-
-// DBG (diagnostic builds only, selected by FEP_PIPE_DBG, never the default): 1 = skip the LDS gather
-// loop, 2 = skip the element-operand loads, 4 = skip the result stores.  Wrong results by design;
-// used to find which resource bounds the kernel.
-template <int CW, bool HAS_DS, bool HAS_S, int DBG = 0>
-__global__ void __launch_bounds__(kBlock)
-p1_node_pipe_kernel(int64_t n_e, int n_tiles,
-                    const int32_t* __restrict__ elist_pad, const uint32_t* __restrict__ seg_pad,
-                    const int32_t* __restrict__ pos_pad, const uint32_t* __restrict__ deg_pad,
-                    const int32_t* __restrict__ fnode_pad,
-                    const uint32_t* __restrict__ codes_pad, const double* __restrict__ geo,
-                    const double* __restrict__ DS, const double* __restrict__ S,
-                    double* __restrict__ data, double* __restrict__ F,
-                    int n_count_blocks, const uint2* __restrict__ blk_counts,
-                    unsigned long long* __restrict__ counts_out) {
-    __shared__ __attribute__((aligned(16))) double rec[kBlock * kRecStride];
-    __shared__ uint32_t codes32[CW * kBlock];
-    const uint16_t* codes = reinterpret_cast<const uint16_t*>(codes32);
-    const int lane = threadIdx.x;
-    const int xcd = blockIdx.x & 7, W = gridDim.x >> 3;
-    const int chunk = (n_tiles + 7) >> 3;
-    const int tile_hi = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
-    int tile = xcd * chunk + (int)(blockIdx.x >> 3);
-    if (counts_out != nullptr && blockIdx.x == gridDim.x - 1) sum_block_counts(n_count_blocks, blk_counts, counts_out);
-    if (tile >= tile_hi) return;
-    const int last = tile_hi - 1;
-
-    // prologue: operands of the first tile, element id of the second (tiles past the end are clamped
-    // to the last one: a few redundant loads instead of a branch around the loads)
-    P1Raw cur;
-    int e_next, pos, fnode;
-    uint32_t seg, deg, cd[CW];
-    {
-        const int64_t o = (int64_t)tile * kBlock + lane;
-        const int tn = tile + W < last ? tile + W : last;
-        const int e_cur = elist_pad[o];
-        e_next = elist_pad[(int64_t)tn * kBlock + lane];
-        seg = seg_pad[o]; pos = pos_pad[o]; deg = deg_pad[o]; fnode = fnode_pad[o];
-#pragma unroll
-        for (int r = 0; r < CW; ++r) cd[r] = codes_pad[((int64_t)tile * CW + r) * kBlock + lane];
-        if (DBG & 2) { cur.g0 = cur.g1 = cur.g2 = cur.g3 = make_double2(1.0, 2.0); for (int k = 0; k < 6; ++k) cur.d[k] = e_cur; for (int k = 0; k < 3; ++k) cur.s[k] = e_cur; }
-        else p1_load_raw<HAS_DS, HAS_S>(cur, e_cur, n_e, geo, DS, S);
-    }
-    // deferred epilogue of the previous tile
-    double q00 = 0.0, q01 = 0.0, q10 = 0.0, q11 = 0.0, qf0 = 0.0, qf1 = 0.0;
-    int64_t q_pos0 = -1, q_deg = 0;
-    int q_fnode = -1;
-    double2* rec2 = reinterpret_cast<double2*>(rec);
-
-    for (;;) {
-        // ---- registers -> LDS (current tile); the only place that waits for the prefetch
-        {
-            const double w = cur.g3.x;
-            double2* r = rec2 + lane * (kRecStride / 2);
-            if (HAS_DS) {
-                r[0] = make_double2(w * cur.d[0], w * cur.d[1]);
-                r[1] = make_double2(w * cur.d[2], w * cur.d[3]);
-                r[2] = make_double2(w * cur.d[4], w * cur.d[5]);
-            }
-            r[3] = make_double2(cur.g0.x, cur.g1.y);      // (d1_0, d2_0)
-            r[4] = make_double2(cur.g0.y, cur.g2.x);      // (d1_1, d2_1)
-            r[5] = make_double2(cur.g1.x, cur.g2.y);      // (d1_2, d2_2)
-            if (HAS_S) {
-                r[6] = make_double2(w * cur.s[0], w * cur.s[1]);
-                r[7] = make_double2(w * cur.s[2], 0.0);
-            }
-#pragma unroll
-            for (int k = 0; k < CW; ++k) codes32[k * kBlock + lane] = cd[k];
-        }
-        const uint32_t seg_c = seg, deg_c = deg;
-        const int pos_c = pos, fnode_c = fnode;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-        // ---- previous tile's results leave now (older than the loads issued next)
-        if (HAS_DS && q_pos0 >= 0 && !(DBG & 4)) {
-            *reinterpret_cast<double2*>(data + q_pos0) = make_double2(q00, q01);
-            *reinterpret_cast<double2*>(data + q_pos0 + 2 * q_deg) = make_double2(q10, q11);
-        }
-        if (HAS_S && q_fnode >= 0) *reinterpret_cast<double2*>(F + 2 * (int64_t)q_fnode) = make_double2(qf0, qf1);
-
-        // ---- next tile's loads in flight (unconditional; nothing below consumes them)
-        const bool has_next = tile + W <= last;
-        const int tile_n = has_next ? tile + W : last;
-        {
-            const int tn2 = tile_n + W < last ? tile_n + W : last;
-            const int64_t o = (int64_t)tile_n * kBlock + lane;
-            const int e_n2 = elist_pad[(int64_t)tn2 * kBlock + lane];
-            seg = seg_pad[o]; pos = pos_pad[o]; deg = deg_pad[o]; fnode = fnode_pad[o];
-#pragma unroll
-            for (int r = 0; r < CW; ++r) cd[r] = codes_pad[((int64_t)tile_n * CW + r) * kBlock + lane];
-            if (DBG & 2) { cur.d[0] = e_next; }
-            else p1_load_raw<HAS_DS, HAS_S>(cur, e_next, n_e, geo, DS, S);
-            e_next = e_n2;
-        }
-
-        // ---- gather the current tile from LDS
-        const int beg = seg_c >> 16, end = seg_c & 0xffffu;
-        double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
-        for (int t = beg; t < ((DBG & 1) ? beg : end); ++t) {
-            const unsigned code = codes[t];
-            const int a = (code >> 2) & 3, b = code & 3;
-            const double2* r = rec2 + (code >> 4) * (kRecStride / 2);
-            const double2 pa = r[3 + a];
-            const double a1 = pa.x, a2 = pa.y;
-            if (HAS_DS) {
-                const double2 pb = r[3 + b], dA = r[0], dB = r[1], dC = r[2];
-                const double b1 = pb.x, b2 = pb.y;
-                const double D00 = dA.x, D01 = dA.y, D02 = dB.x, D11 = dB.y, D12 = dC.x, D22 = dC.y;
-                const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
-                const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
-                k00 += r00 * b1 + r02 * b2;
-                k01 += r01 * b2 + r02 * b1;
-                k10 += r10 * b1 + r12 * b2;
-                k11 += r11 * b2 + r12 * b1;
-            }
-            if (HAS_S && fnode_c >= 0) {
-                const double2 sA = r[6], sB = r[7];
-                f0 += a1 * sA.x + a2 * sB.x;
-                f1 += a2 * sA.y + a1 * sB.x;
-            }
-        }
-        q00 = k00; q01 = k01; q10 = k10; q11 = k11; qf0 = f0; qf1 = f1;
-        q_pos0 = pos_c;
-        q_deg = deg_c;
-        q_fnode = fnode_c;
-        if (!has_next) break;                                  // uniform
-        asm volatile("s_barrier" ::: "memory");                // every wave is done reading this tile's LDS
-        tile = tile_n;
-    }
-    if (HAS_DS && q_pos0 >= 0) {
-        *reinterpret_cast<double2*>(data + q_pos0) = make_double2(q00, q01);
-        *reinterpret_cast<double2*>(data + q_pos0 + 2 * q_deg) = make_double2(q10, q11);
-    }
-    if (HAS_S && q_fnode >= 0) *reinterpret_cast<double2*>(F + 2 * (int64_t)q_fnode) = make_double2(qf0, qf1);
 }
 
 }  // namespace fep

@@ -1,0 +1,99 @@
+"""
+End-to-end callers of the hot path (BASELINE configs 2 and 3 at the sizes the reference itself can run):
+the re-stated load-stepping / Newton drivers against traces recorded from the reference drivers.
+
+Tolerance: displacements 1e-10 relative to the field's maximum (north_star), load history exact,
+footing pressure 1e-9 relative.  The linear solves differ (SciPy SuperLU vs the reference's dense LAPACK),
+Newton converges both to criterion < 1e-12.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dp_p1_level1_driver_vs_reference_trace(fep):
+    g = load_golden('dp_p1_level1_trace')
+    h = fep.solve_strip_footing('P1', level=1)
+    assert len(h['zeta']) == 16 == len(g['zeta'])
+    assert np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)                 # same adaptive step sequence
+    assert h['n_calls'] == int(g['n_calls']) == 125                             # same number of return-map calls
+    # the reference logs the pressure of step k at the start of step k+1 (DP:1034)
+    assert np.abs(np.array(h['pressure'][:15]) - g['pressure'][1:16]).max() <= 1e-9 * np.abs(g['pressure']).max()
+    assert relerr(h['pressure'][14], 16.83867398886026) <= 1e-9                 # SURVEY 8c pin (zeta = 0.52)
+    for k in range(16):
+        assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-10, k
+    assert h['counts'][-1] == tuple(g['counts'][-1]) == (599, 171)
+    assert relerr(h['Ep'], g['Ep_final']) <= 1e-9
+
+
+def test_tsx_p1_driver_vs_reference_replay(fep):
+    g = load_golden('tsx')
+    h = fep.solve_tsx_tunnel(g['coord'], g['elem'], 'P1')
+    assert len(h['zeta']) == 17 and np.allclose(h['zeta'], g['p1_zeta'], rtol=0, atol=1e-15)
+    assert h['n_plast'] == g['p1_nplast'].tolist() == [0] * 13 + [1, 1, 2, 3]
+    assert relerr(h['F0'], g['p1_F0']) <= 1e-12
+    assert relerr(h['U'][12], g['p1_U_step13']) <= 1e-10
+    assert relerr(h['U'][-1], g['p1_U_final']) <= 1e-10
+    assert abs(h['displ'][-1] - (-0.0019794496707526746)) <= 1e-10 * 0.0019794496707526746     # SURVEY 8c pin
+
+
+def test_tsx_p2_first_steps(fep):
+    """P2 mesh (midpoints from the reference generator, fixture): elastic steps are linear in zeta."""
+    g = load_golden('tsx')
+    h = fep.solve_tsx_tunnel(g['p2_coord'], g['p2_elem'], 'P2', n_load_steps=17)
+    assert len(h['zeta']) == 17
+    assert np.abs(h['F0'].T[h['Q'].T] - g['f0q']).max() <= 2e-4 * np.abs(g['f0q']).max()       # f0q.csv
+    el = [k for k, n in enumerate(h['n_plast']) if n == 0]
+    assert len(el) >= 5
+    for k in el[1:]:
+        assert relerr(h['U'][k] / h['zeta'][k], h['U'][el[0]] / h['zeta'][el[0]]) <= 1e-9
+
+
+def test_transform_matches_definition(fep):
+    rng = np.random.default_rng(0)
+    mesh = fep.square_mesh(3, 'P2', 3)
+    elem = mesh['elements']
+    w = rng.uniform(1, 2, elem.shape[1] * 7)
+    q = rng.normal(size=w.size)
+    got = fep.transform(q, elem, w)
+    n_n = mesh['coordinates'].shape[1]
+    f1 = np.zeros(n_n); f2 = np.zeros(n_n)
+    for e in range(elem.shape[1]):
+        for qq in range(7):
+            k = e * 7 + qq
+            for a in range(6):
+                f1[elem[a, e]] += w[k] * q[k]
+                f2[elem[a, e]] += w[k]
+    assert np.allclose(got, f1 / f2, rtol=1e-14)
+
+
+def test_config2_65k_p1_single_load_step(fep):
+    """BASELINE configs[1]: ~65k P1 elements (N=181), first load step, Newton to 1e-12; the converged
+    iterate's hot-path outputs are checked against the oracle on the same displacement."""
+    from oracle import fep_oracle as orc
+    from conftest import dp_materials
+    h = fep.solve_strip_footing('P1', n_cells=181, max_steps=1)
+    assert len(h['zeta']) == 1 and h['zeta'][0] == 1 / 1000 and h['newton_its'][0] <= 25
+    mesh = h['mesh']
+    elem, coord = mesh['elements'], mesh['coordinates']
+    assert elem.shape[1] == 65522
+    U = h['U'][0]
+    d1, d2, wf = fep.element_tables('P1')
+    sh, bu, eta, c = dp_materials(elem.shape[1])
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)
+    E, cp, K_t, F = orc.hot_path(U, np.zeros((4, elem.shape[1])),
+                                 dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=sh, bulk=bu, eta=eta, c=c))
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh, bu, eta, c)
+    r = ctx.step(U, np.zeros((4, elem.shape[1])), want=('s', 'ds', 'ind_p', 'K', 'F'))
+    assert cp['n_smooth'] + cp['n_apex'] > 0 and (r['n_smooth'], r['n_apex']) == (cp['n_smooth'], cp['n_apex'])
+    assert np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['s'], cp['s']) <= 1e-13 and relerr(r['ds'], cp['ds']) <= 1e-13
+    assert np.abs((r['K'] - K_t).data).max() <= 1e-12 * np.abs(K_t.data).max()
+    assert relerr(r['F'], F) <= 1e-12
+    # converged: the residual vanishes on the free DOFs
+    qf = mesh['Q'].flatten(order='F')
+    assert np.abs(r['F'][qf]).max() <= 1e-8 * np.abs(r['F']).max()
