@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cells', type=int, default=N_CELLS, help='cells per side of the per-GPU square')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     args = ap.parse_args()
 
     import torch
@@ -91,11 +92,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if os.environ.get('FEP_BENCH_SINGLE_DEVICE'):      # rehearsal of the N>1 path on a one-GPU box: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     fep = importlib.import_module('fem-elastoplasticity_amd')
     fep.lib()                                      # fails loudly if the HIP extension is missing
@@ -171,7 +177,9 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tpath))
+                if tj.get('elements_per_gpu', 1002528) == n_int and route == 'node':
+                    traffic = tj.get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         line = {

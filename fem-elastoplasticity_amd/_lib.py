@@ -47,6 +47,8 @@ PROTOTYPES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_gather_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_scatter_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_ctx_profile_begin': (C.c_int, [C.c_void_p]),
     'fep_ctx_profile_end': (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
 }

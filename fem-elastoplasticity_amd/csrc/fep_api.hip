@@ -467,12 +467,23 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             const char* pth = std::getenv("FEP_P1_PATH");
             c->lds_L = (int)((lmax + 1) & ~(size_t)1);
             // 15 doubles per staged element; fall back to the direct-gather kernel when a list would not fit
-            c->p1_lds = lmax < 4096 && (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 <= 96 * 1024 &&
+            // the staged kernel holds <= 2 elements and <= 4 gather codes per lane in registers
+            c->p1_lds = lmax <= 2 * (size_t)TILE && cmax <= 4 * (size_t)TILE &&
+                        (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 <= 96 * 1024 &&
                         !(pth && std::strcmp(pth, "node_direct") == 0);
             if (c->p1_lds) {
-                CK(upload(&c->wg_eptr, eptr.data(), (int64_t)eptr.size()));
-                CK(upload(&c->wg_elist, elist.data(), (int64_t)elist.size()));
-                CK(upload(&c->perm_l, perm_l.data(), (int64_t)perm_l.size()));
+                // fixed per-tile strides (lds_L list entries, lds_C codes); unused slots repeat a valid entry
+                const int64_t LP = c->lds_L, CP = c->lds_C;
+                std::vector<int32_t> elist_pad((size_t)(n_wg * LP));
+                std::vector<uint16_t> codes_pad((size_t)(n_wg * CP), 0);
+                for (int64_t g = 0; g < n_wg; ++g) {
+                    std::fill(elist_pad.begin() + g * LP, elist_pad.begin() + (g + 1) * LP, lists[g].empty() ? 0 : lists[g][0]);
+                    std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * LP);
+                    const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                    std::copy(perm_l.begin() + S.segptr[b0], perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * CP);
+                }
+                CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
+                CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
             }
         }
         CK(dmalloc(&c->geo, 8 * n_e));
@@ -640,7 +651,7 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
             HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB>,                                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
         hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB>), dim3(8 * chunk), dim3(TPB), lds, st, c->n_blk, c->n_e,      \
-                           c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist, c->geo,            \
+                           c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist, c->geo,              \
                            k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks,           \
                            c->blk_counts, counts_d, (long long*)nullptr);                                               \
     } while (0)
@@ -766,6 +777,26 @@ extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s
     return FEP_OK;
 }
 
+extern "C" int fep_gather_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* idx_d, double* dst_d) {
+    if (n < 0 || (n > 0 && (!src_d || !idx_d || !dst_d))) return FEP_EINVAL;
+    FEP_TRY(set_device(device_id));
+    if (n == 0) return FEP_OK;
+    hipLaunchKernelGGL(gather_or_zero_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, src_d, idx_d, dst_d);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+extern "C" int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* src_idx_d,
+                               const int32_t* dst_idx_d, double* dst_d) {
+    if (n < 0 || (n > 0 && (!src_d || !src_idx_d || !dst_idx_d || !dst_d))) return FEP_EINVAL;
+    FEP_TRY(set_device(device_id));
+    if (n == 0) return FEP_OK;
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, src_d, src_idx_d,
+                       dst_idx_d, dst_d);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
 extern "C" int fep_ctx_profile_begin(fep_ctx* c) {
     if (!c) return FEP_EINVAL;
     for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -812,7 +843,7 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
     const int chunk = (n_wg + 7) / 8;
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL((p1_node_lds_kernel<true, 256>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
-                           c->n_blk, c->n_e, c->lds_L, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_eptr, c->wg_elist,
+                           c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,
                            c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0, (const uint2*)nullptr,
                            (unsigned long long*)nullptr, st.as<long long>());
         HIP_TRY(hipGetLastError());

@@ -531,15 +531,15 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 // first stages the per-element operands of the elements it touches — w*D (6), w*s (3), dphi (6) —
 // into LDS with coalesced loads over its precomputed, sorted element list, then every lane
 // gathers from LDS only.
-//   wg_eptr[n_wg+1], wg_elist[...]   sorted unique elements per workgroup
-//   perm_l[t] = (local element index << 4) | a << 2 | b      (uint16)
+//   wg_elist[wg*L + i]   sorted unique elements of the workgroup, padded to L with its first element
+//   perm_l[wg*C + k]     gather codes (local element index << 4) | a << 2 | b   (uint16), padded to C
 //   LDS: rec[15][L] doubles, L = max list length, then the workgroup's gather codes (uint16)
 // ---------------------------------------------------------------------------------------
 template <bool DIAG, int TPB>
 __global__ void __launch_bounds__(TPB)
-p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict__ segptr,
+p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
                    const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
-                   const int32_t* __restrict__ ncol, const int32_t* __restrict__ wg_eptr,
+                   const int32_t* __restrict__ ncol,
                    const int32_t* __restrict__ wg_elist, const double* __restrict__ geo,
                    const double* __restrict__ DS, const double* __restrict__ S,
                    double* __restrict__ data, double* __restrict__ F,
@@ -557,38 +557,77 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict_
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (counts_out != nullptr && blockIdx.x == gridDim.x - 1) sum_block_counts(n_count_blocks, blk_counts, counts_out);
     if (wg >= n_wg) return;
-    // everything that does not depend on the staged data is requested up front: the lane's own segment
-    // bounds / meta word, and the workgroup's contiguous range of gather codes (into LDS)
+    // Two dependent memory levels only: every table is padded to a fixed per-tile stride (element list:
+    // L entries, gather codes: C entries, unused slots repeat a valid entry), so all first-level
+    // addresses are functions of (tile, lane) and go out together at kernel entry; the operand loads
+    // follow as soon as the list entries land.
     const int64_t sb = (int64_t)wg * TPB + threadIdx.x;
     const bool live = sb < n_blk;
-    const int64_t sb_first = (int64_t)wg * TPB;
-    const int64_t sb_last = sb_first + TPB < n_blk ? sb_first + TPB : n_blk;
-    const int32_t t0 = segptr[sb_first], t1 = segptr[sb_last];
+    constexpr int EPT = 2;                              // staged elements per lane (host guarantees L <= EPT*TPB)
+    constexpr int CPT = 4;                              // gather codes per lane      (host guarantees C <= CPT*TPB)
+    const int ecnt = L, ncodes = C;
+    int64_t el[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int i = r * TPB + (int)threadIdx.x;
+        el[r] = wg_elist[(int64_t)wg * L + (i < L ? i : 0)];
+    }
     const int32_t beg = live ? segptr[sb] : 0, end = live ? segptr[sb + 1] : 0;
     const uint32_t m = live ? meta[sb] : 0u;
+    const int32_t fnode = (live && ((m >> 15) & 1u)) ? ncol[sb] : -1;
+    uint16_t cd[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int i = r * TPB + (int)threadIdx.x;
+        cd[r] = perm_l[(int64_t)wg * C + (i < C ? i : 0)];
+    }
+    __shared__ int32_t t0_sh;
+    if (threadIdx.x == 0) t0_sh = beg;                  // first code of the tile (read after the barrier)
+    if (DIAG) { st1 = (long long)__builtin_amdgcn_s_memtime(); }
     uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
-    for (int i = threadIdx.x; i < t1 - t0; i += TPB) codes[i] = perm_l[t0 + i];
-    if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st1 = (long long)__builtin_amdgcn_s_memtime(); }   // prologue loads landed
-    const int ebeg = wg_eptr[wg], ecnt = wg_eptr[wg + 1] - ebeg;
-    for (int i = threadIdx.x; i < ecnt; i += TPB) {
-        const int64_t e = wg_elist[ebeg + i];
-        if (DIAG && i == (int)threadIdx.x) { __builtin_amdgcn_s_waitcnt(0); st2 = (long long)__builtin_amdgcn_s_memtime(); }  // list entry landed
-        const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
-        const double2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-        const double w = g3.x;
-        rec[9 * L + i] = g0.x;  rec[10 * L + i] = g0.y; rec[11 * L + i] = g1.x;     // d1[0..2]
-        rec[12 * L + i] = g1.y; rec[13 * L + i] = g2.x; rec[14 * L + i] = g2.y;     // d2[0..2]
-        if (DS) {
-            rec[i] = w * DS[e];                 rec[L + i] = w * DS[n_e + e];      rec[2 * L + i] = w * DS[2 * n_e + e];
-            rec[3 * L + i] = w * DS[4 * n_e + e]; rec[4 * L + i] = w * DS[5 * n_e + e]; rec[5 * L + i] = w * DS[8 * n_e + e];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int i = r * TPB + (int)threadIdx.x;
+        if (i < ecnt) {
+            const int64_t e = el[r];
+            if (DIAG && r == 0) { st2 = (long long)__builtin_amdgcn_s_memtime(); }
+            const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
+            const double2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+            double dv[6], sv[3];
+            if (DS) {
+                dv[0] = DS[e]; dv[1] = DS[n_e + e]; dv[2] = DS[2 * n_e + e];
+                dv[3] = DS[4 * n_e + e]; dv[4] = DS[5 * n_e + e]; dv[5] = DS[8 * n_e + e];
+            }
+            if (S) { sv[0] = S[e]; sv[1] = S[n_e + e]; sv[2] = S[2 * n_e + e]; }
+            if (r == 0) {                                 // codes -> LDS while the operands are in flight
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const int ci = q * TPB + (int)threadIdx.x;
+                    if (ci < ncodes) codes[ci] = cd[q];
+                }
+            }
+            const double w = g3.x;
+            rec[9 * L + i] = g0.x;  rec[10 * L + i] = g0.y; rec[11 * L + i] = g1.x;     // d1[0..2]
+            rec[12 * L + i] = g1.y; rec[13 * L + i] = g2.x; rec[14 * L + i] = g2.y;     // d2[0..2]
+            if (DS) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) rec[k * L + i] = w * dv[k];
+            }
+            if (S) { rec[6 * L + i] = w * sv[0]; rec[7 * L + i] = w * sv[1]; rec[8 * L + i] = w * sv[2]; }
+        } else if (r == 0) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int ci = q * TPB + (int)threadIdx.x;
+                if (ci < ncodes) codes[ci] = cd[q];
+            }
         }
-        if (S) { rec[6 * L + i] = w * S[e]; rec[7 * L + i] = w * S[n_e + e]; rec[8 * L + i] = w * S[2 * n_e + e]; }
     }
     if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st3 = (long long)__builtin_amdgcn_s_memtime(); }   // this wave's staging done
     __syncthreads();
     if (DIAG) st4 = (long long)__builtin_amdgcn_s_memtime();                                       // barrier released
     if (!live) return;
-    const bool want_f = ((m >> 15) & 1u) && F != nullptr && S != nullptr;
+    const int32_t t0 = t0_sh;
+    const bool want_f = fnode >= 0 && F != nullptr && S != nullptr;
     double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
     for (int32_t t = beg; t < end; ++t) {
         const unsigned code = codes[t - t0];
@@ -616,13 +655,28 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, const int32_t* __restrict_
         *reinterpret_cast<double2*>(data + pos0) = make_double2(k00, k01);
         *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(k10, k11);
     }
-    if (want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol[sb]) = make_double2(f0, f1);
+    if (want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)fnode) = make_double2(f0, f1);
     if (DIAG && threadIdx.x == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         long long* o = stamps + (int64_t)wg * 8;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = (long long)__builtin_amdgcn_s_memtime();
-        o[6] = blockIdx.x; o[7] = ecnt;
+        o[6] = blockIdx.x; o[7] = L;
     }
+}
+
+// Interface exchange helpers (multi-GPU): pack the rank's interface DOFs into the all-reduce buffer
+// (slots owned by other ranks are written as zeros, so no separate memset) and unpack the sums.
+__global__ void __launch_bounds__(kBlock)
+gather_or_zero_kernel(int64_t n, const double* __restrict__ src, const int32_t* __restrict__ idx, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) { const int32_t j = idx[i]; dst[i] = j >= 0 ? src[j] : 0.0; }
+}
+
+__global__ void __launch_bounds__(kBlock)
+scatter_kernel(int64_t n, const double* __restrict__ src, const int32_t* __restrict__ src_idx,
+               const int32_t* __restrict__ dst_idx, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[dst_idx[i]] = src[src_idx[i]];
 }
 
 }  // namespace fep

@@ -62,21 +62,34 @@ class Partition:
         F_local[self.iface_local_dofs] = buf[torch.from_numpy(self.iface_slot_dofs)].numpy()
         return F_local
 
-    # ---- device-resident exchange (torch tensors on the context's GPU; RCCL) --------------------
-    def exchange_force_(self, F_local_t, group=None):
-        """In-place: interface DOFs of the local force tensor become the sum over all ranks."""
+    # ---- device-resident exchange (torch tensors on the rank's GPU; RCCL) --------------------------
+    def exchange_force_(self, F_local_t, group=None, stream=None):
+        """In-place: interface DOFs of the local force tensor become the sum over all ranks.
+        pack kernel (other ranks' slots written as zero) -> all-reduce -> unpack kernel."""
         import torch
         import torch.distributed as dist
+        from . import _lib
+        dev = F_local_t.device
         if self._t is None:
-            dev = F_local_t.device
-            self._t = (torch.from_numpy(self.iface_local_dofs).to(dev), torch.from_numpy(self.iface_slot_dofs).to(dev),
-                       torch.zeros(2 * self.n_iface, dtype=torch.float64, device=dev))
-        loc, slot, buf = self._t
-        buf.zero_()
-        buf.index_copy_(0, slot, F_local_t.index_select(0, loc))
+            pack = np.full(2 * self.n_iface, -1, dtype=np.int32)
+            pack[self.iface_slot_dofs] = self.iface_local_dofs
+            self._t = (torch.from_numpy(pack).to(dev), torch.from_numpy(self.iface_slot_dofs.astype(np.int32)).to(dev),
+                       torch.from_numpy(self.iface_local_dofs.astype(np.int32)).to(dev),
+                       torch.empty(2 * self.n_iface, dtype=torch.float64, device=dev))
+        pack, slot, loc, buf = self._t
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        l = _lib.lib()
+        _lib.check(l.fep_gather_f64(dev.index, st, buf.numel(), F_local_t.data_ptr(), pack.data_ptr(), buf.data_ptr()),
+                   'fep_gather_f64')
         if self.world > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        F_local_t.index_copy_(0, loc, buf.index_select(0, slot))
+            if dist.get_backend(group) == 'gloo':                  # rehearsal backend: stage through the host
+                tmp = buf.cpu()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+                buf.copy_(tmp)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        _lib.check(l.fep_scatter_f64(dev.index, st, slot.numel(), buf.data_ptr(), slot.data_ptr(), loc.data_ptr(),
+                                     F_local_t.data_ptr()), 'fep_scatter_f64')
         return F_local_t
 
 

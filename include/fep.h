@@ -160,6 +160,14 @@ int fep_assemble_dev(fep_ctx* ctx, void* stream, const double* ds_d, const doubl
 int fep_assemble_host(fep_ctx* ctx, const double* ds_h, const double* s_h,
                       double* k_data_h, double* f_out_h);
 
+/* ---- multi-GPU interface exchange helpers (no reference counterpart: the reference is single-process) ----
+ * Pack / unpack of the interface DOFs around the RCCL all-reduce of the internal force (sharding.py):
+ *   fep_gather_f64   dst[i] = idx[i] >= 0 ? src[idx[i]] : 0      (i < n)
+ *   fep_scatter_f64  dst[dst_idx[i]] = src[src_idx[i]]            (i < n; dst_idx must be unique) */
+int fep_gather_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* idx_d, double* dst_d);
+int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* src_idx_d,
+                    const int32_t* dst_idx_d, double* dst_d);
+
 /* ---- in-situ kernel timing (bench.py's roofline figure) --------------------------------
  * Between fep_ctx_profile_begin and fep_ctx_profile_end every fep_step_dev / fep_assemble_dev call
  * brackets each of its kernels with HIP events on the launch stream (the kernels run in their real

@@ -1,0 +1,55 @@
+"""Element sharding on the GPU, in one process: the shards of a world of 2/3 are built and stepped one after
+the other on cuda:0, the interface forces are summed the way the all-reduce does, and everything is compared
+with the single-context result on the global mesh.  (The multi-process exchange itself is covered on CPU by
+tests/test_sharding_gloo.py.)"""
+import numpy as np
+import pytest
+
+from conftest import dp_materials, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('t,nx,ny,world', [('P1', 40, 60, 2), ('P1', 30, 45, 3), ('Q1', 24, 36, 2)])
+def test_shards_reproduce_global_step(fep, t, nx, ny, world):
+    mesh = fep.rect_mesh(nx, ny, t, 10, 15)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n_q = fep.ELEMENT_SHAPE[fep.LagrangeElementType[t]][1]
+    n_int = elem.shape[1] * n_q
+    sh, bu, eta, c = dp_materials(n_int)
+    x, y = coord
+    U = np.array([2.5e-4 * y * (x / 10) + 1.2e-4 * x * (y > 5), -1.5e-4 * y * (x < 5) + 2.0e-4 * y * (x >= 5)])
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh, bu, eta, c)
+    ref = ctx.step(U, np.zeros((4, n_int)), want=('s', 'ds', 'ind_p', 'K', 'F'))
+    assert ref['n_smooth'] > 0 and ref['n_apex'] > 0
+    n_dof = 2 * coord.shape[1]
+    F_sum = np.zeros(n_dof)
+    K_sum = None
+    shards = []
+    for r in range(world):
+        sc = fep.ShardedContext(elem, coord, r, world)
+        sc.set_materials(sh, bu, eta, c)
+        out = sc.ctx.step(U[:, sc.nodes], np.zeros((4, sc.ctx.n_int)), want=('s', 'ds', 'ind_p', 'K', 'F'))
+        sl = sc.local_point_slice()
+        # integration-point data is owned by exactly one rank and equals the global result
+        assert np.array_equal(out['ind_p'], ref['ind_p'][sl])
+        assert relerr(out['s'], ref['s'][:, sl]) <= 1e-13 and relerr(out['ds'], ref['ds'][:, sl]) <= 1e-13
+        dofs = (2 * sc.nodes[:, None] + np.arange(2)[None, :]).ravel()
+        F_sum[dofs] += out['F']
+        Kg = out['K'].tocoo()
+        import scipy.sparse as ssp
+        Kr = ssp.coo_matrix((Kg.data, (dofs[Kg.row], dofs[Kg.col])), shape=(n_dof, n_dof)).tocsr()
+        K_sum = Kr if K_sum is None else K_sum + Kr
+        shards.append((sc, out['F'], dofs))
+    assert relerr(F_sum, ref['F']) <= 1e-12                         # partial forces sum to the global force
+    assert np.abs((K_sum - ref['K']).data).max() <= 1e-12 * np.abs(ref['K'].data).max()    # sub-assembled K
+    # what the all-reduce leaves on every rank: summed interface DOFs
+    buf = np.zeros(2 * shards[0][0].n_iface)
+    for sc, F, _ in shards:
+        buf[sc.iface_slot_dofs] += F[sc.iface_local_dofs]
+    for sc, F, dofs in shards:
+        F = F.copy()
+        F[sc.iface_local_dofs] = buf[sc.iface_slot_dofs]
+        assert relerr(F, ref['F'][dofs]) <= 1e-12
+        sc.close()
