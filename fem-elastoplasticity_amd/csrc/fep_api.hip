@@ -50,6 +50,9 @@ struct fep_ctx {
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
     int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
+    bool gn = false;                                    // node route for P2 / Q1 / Q2 (point_kernel + node_lds_kernel)
+    int gn_tile = 256;
+    size_t gn_lds = 0;
     int lds_L = 0, lds_C = 0;                           // staged elements / gather codes per workgroup (max)
     // device, scratch rewritten by every step
     double *Kc = nullptr, *fe = nullptr;
@@ -496,6 +499,71 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         }
         c->n_count_blocks = (int)grid_for(n_e, kBlock);
     } else {
+        // P2 / Q1 / Q2: the COO route is the default; FEP_GEN_PATH=node selects the node route (measured on
+        // MI355X, 1 M elements: Q1 0.276 vs 0.286 ms, P2 1.80 vs 1.30 ms, Q2 0.41 vs 0.34 ms per step — its LDS
+        // gather costs n_q times the P1 one)
+        const char* gp = std::getenv("FEP_GEN_PATH");
+        const bool want_gn = (elem_type == FEP_P2 || elem_type == FEP_Q1 || elem_type == FEP_Q2) &&
+                             gp && std::strcmp(gp, "node") == 0 && r == FEP_OK;
+        for (int TILE : {256, 128}) {
+            if (!want_gn || c->gn) break;
+            // per-tile sorted unique element lists and 16-bit gather codes (local element << 8 | a << 4 | b)
+            const int64_t n_wg = (c->n_blk + TILE - 1) / TILE;
+            std::vector<std::vector<int32_t>> lists(n_wg);
+            std::vector<uint16_t> perm_l(S.perm.size());
+            const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> th;
+            std::vector<int> bad(nthreads, 0);
+            for (int w = 0; w < nthreads; ++w)
+                th.emplace_back([&, w]() {
+                    for (int64_t g = n_wg * w / nthreads; g < n_wg * (w + 1) / nthreads; ++g) {
+                        const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                        const int32_t t0 = S.segptr[b0], t1 = S.segptr[b1];
+                        std::vector<int32_t>& l = lists[g];
+                        l.reserve(t1 - t0);
+                        for (int32_t t = t0; t < t1; ++t) l.push_back((int32_t)(S.perm[t] % n_e));
+                        std::sort(l.begin(), l.end());
+                        l.erase(std::unique(l.begin(), l.end()), l.end());
+                        if (l.size() > 256) { bad[w] = 1; continue; }
+                        for (int32_t t = t0; t < t1; ++t) {
+                            const int64_t ab = S.perm[t] / n_e, e = S.perm[t] % n_e;
+                            const int32_t loc = (int32_t)(std::lower_bound(l.begin(), l.end(), (int32_t)e) - l.begin());
+                            perm_l[t] = (uint16_t)((loc << 8) | ((int)(ab / n_p) << 4) | (int)(ab % n_p));
+                        }
+                    }
+                });
+            for (auto& t : th) t.join();
+            size_t lmax = 0, cmax = 0;
+            for (int64_t g = 0; g < n_wg; ++g) {
+                lmax = std::max(lmax, lists[g].size());
+                const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                cmax = std::max(cmax, (size_t)(S.segptr[b1] - S.segptr[b0]));
+            }
+            const int L = (int)lmax, C = (int)((cmax + 7) & ~(size_t)7);
+            const size_t lds = ((size_t)(9 + 2 * n_p) * L * n_q + 2 * (size_t)n_p * n_q + n_q + (n_q & 1)) * sizeof(double) +
+                               (size_t)C * sizeof(uint16_t);
+            bool ok = lmax <= 256 && lds <= 64 * 1024;
+            for (int b : bad) ok = ok && !b;
+            if (!ok) continue;
+            c->gn = true; c->gn_tile = TILE; c->lds_L = L; c->lds_C = C; c->gn_lds = lds;
+            std::vector<int32_t> elist_pad((size_t)(n_wg * L));
+            std::vector<uint16_t> codes_pad((size_t)(n_wg * C), 0);
+            for (int64_t g = 0; g < n_wg; ++g) {
+                std::fill(elist_pad.begin() + g * L, elist_pad.begin() + (g + 1) * L, lists[g].empty() ? 0 : lists[g][0]);
+                std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * L);
+                const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                std::copy(perm_l.begin() + S.segptr[b0], perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * C);
+            }
+            CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
+            CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
+            CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
+            std::vector<double> xy(2 * (size_t)n_n);
+            for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
+            CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
+            c->n_count_blocks = (int)grid_for(c->n_int, kBlock);
+        }
+    }
+    if (!c->p1_node && !c->gn) {
         CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
         CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
         CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
@@ -670,6 +738,50 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
     return FEP_OK;
 }
 
+// node route for P2 / Q1 / Q2: assembly kernel
+static int launch_gn_node(fep_ctx* c, hipStream_t st, const double* ds, const double* s, double* k_data, double* f_out,
+                          unsigned long long* counts_d, bool* counts_done) {
+    FEP_TRY(prof_mark(c, st));
+    if (counts_done) *counts_done = false;
+    if ((k_data && ds) || (f_out && s)) {
+        const int n_wg = (int)grid_for(c->n_blk, c->gn_tile);
+        const int chunk = (n_wg + 7) / 8;
+        const size_t lds = c->gn_lds;
+#define GN(NP, NQ, TPB)                                                                                                  \
+    do {                                                                                                                 \
+        if (lds > 48 * 1024)                                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)node_lds_kernel<NP, NQ, TPB>,                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+        hipLaunchKernelGGL((node_lds_kernel<NP, NQ, TPB>), dim3(8 * chunk), dim3(TPB), lds, st, c->n_blk, c->n_e,        \
+                           c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist, c->elem, c->xy,      \
+                           c->dh1, c->dh2, c->wf, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out, n_wg,       \
+                           c->n_count_blocks, c->blk_counts, counts_d);                                                  \
+    } while (0)
+        const bool t256 = c->gn_tile == 256;
+        switch (c->elem_type) {
+            case FEP_P2: if (t256) GN(6, 7, 256); else GN(6, 7, 128); break;
+            case FEP_Q1: if (t256) GN(4, 4, 256); else GN(4, 4, 128); break;
+            case FEP_Q2: if (t256) GN(8, 9, 256); else GN(8, 9, 128); break;
+            default: return FEP_EINVAL;
+        }
+#undef GN
+        HIP_TRY(hipGetLastError());
+        if (counts_done) *counts_done = counts_d != nullptr;
+    }
+    FEP_TRY(prof_mark(c, st));
+    FEP_TRY(prof_mark(c, st));
+    return FEP_OK;
+}
+
+template <int NP, int NQ>
+static int launch_point(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept, double* eout,
+                        double* s, double* ds, uint8_t* indp, uint2* blk) {
+    hipLaunchKernelGGL((point_kernel<NP, NQ>), dim3(grid_for(c->n_int, kBlock)), dim3(kBlock), 0, st, c->n_e, c->elem,
+                       c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear, c->bulk, c->eta, c->c, accept, eout, s, ds, indp, blk);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
 extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const double* e0_h,
                             double* ep_prev_d, int accept, double* e_out_d, double* s_d, double* ds_d,
                             uint8_t* ind_p_d, double* k_data_d, double* f_out_d, int64_t* counts_d) {
@@ -699,6 +811,26 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
         FEP_TRY(launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, cnt, &counted));
         return counted ? FEP_OK : launch_counts(c, st, cnt);
     }
+    if (c->gn) {
+        if (k_data_d && !ds_d) {
+            if (!c->ds_int) FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int));
+            ds_d = c->ds_int;
+        }
+        if (f_out_d && !s_d) {
+            if (!c->s_int) FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int));
+            s_d = c->s_int;
+        }
+        FEP_TRY(prof_mark(c, st));
+        switch (c->elem_type) {
+            case FEP_P2: FEP_TRY((launch_point<6, 7>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk))); break;
+            case FEP_Q1: FEP_TRY((launch_point<4, 4>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk))); break;
+            case FEP_Q2: FEP_TRY((launch_point<8, 9>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk))); break;
+            default: return FEP_EINVAL;
+        }
+        bool counted = false;
+        FEP_TRY(launch_gn_node(c, st, ds_d, s_d, k_data_d, f_out_d, cnt, &counted));
+        return counted ? FEP_OK : launch_counts(c, st, cnt);
+    }
     FEP_TRY(prof_mark(c, st));
 #define CALL(NP, NQ)                                                                                     \
     FEP_TRY((launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk, \
@@ -718,6 +850,10 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
     if (c->p1_node) {
         FEP_TRY(prof_mark(c, st));
         return launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, nullptr, nullptr);
+    }
+    if (c->gn) {
+        FEP_TRY(prof_mark(c, st));
+        return launch_gn_node(c, st, ds_d, s_d, k_data_d, f_out_d, nullptr, nullptr);
     }
     const E0 e0 = make_e0(nullptr);
     FEP_TRY(prof_mark(c, st));

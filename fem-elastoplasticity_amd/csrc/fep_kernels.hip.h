@@ -664,6 +664,184 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Node route for elements with several integration points (P2, Q1, Q2): the same two-kernel split as
+// the P1 fast path, with the geometry recomputed from the node coordinates (gathered through L2)
+// instead of streaming dphi (16*n_p bytes per point) from HBM.
+//
+//   point_kernel<NP,NQ>      one lane per integration point: Jacobian + dphi at its quadrature point
+//                            (same operation order as geometry_kernel), strain, return map; writes s, ds, ind_p.
+//   node_lds_kernel<NP,NQ>   one workgroup per tile of TPB node-pair blocks: stages, for every (element, q)
+//                            of the elements the tile touches, w*D (6), w*s (3) and dphi (2*NP) into LDS
+//                            [field][slot], slot = local element * NQ + q, then every lane sums
+//                            sum_q w B_a^T DS B_b over its block's contributions in fixed order.
+//   gather code = local element << 8 | a << 4 | b  (uint16; <= 256 elements per tile, n_p <= 16)
+// ---------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void geometry_at_q(const double* __restrict__ t1, const double* __restrict__ t2, double wfq,
+                                              int q, int nq, const double x[NP], const double y[NP],
+                                              double d1[NP], double d2[NP], double& w) {
+#pragma clang fp contract(off)
+    double j11 = 0.0, j12 = 0.0, j21 = 0.0, j22 = 0.0;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {                       // DP:530-533
+        const double h1 = t1[a * nq + q], h2 = t2[a * nq + q];
+        j11 = j11 + x[a] * h1; j12 = j12 + y[a] * h1; j21 = j21 + x[a] * h2; j22 = j22 + y[a] * h2;
+    }
+    const double det = j11 * j22 - j12 * j21;
+    const double i11 = j22 / det, i12 = -j12 / det, i21 = -j21 / det, i22 = j11 / det;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+        const double h1 = t1[a * nq + q], h2 = t2[a * nq + q];
+        d1[a] = i11 * h1 + i12 * h2;                     // DP:545-546
+        d2[a] = i21 * h1 + i22 * h2;
+    }
+    w = fabs(det) * wfq;                                 // DP:585
+}
+
+template <int NP, int NQ>
+__global__ void __launch_bounds__(kBlock)
+point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __restrict__ xy,
+             const double* __restrict__ dh1, const double* __restrict__ dh2, const double* __restrict__ wf,
+             const double* __restrict__ U, E0 e0, double* __restrict__ ep,
+             const double* __restrict__ shear, const double* __restrict__ bulk,
+             const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+             double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS,
+             uint8_t* __restrict__ indp, uint2* blk_counts) {
+    __shared__ double t1[NP * NQ], t2[NP * NQ], tw[NQ];
+    for (int i = threadIdx.x; i < NP * NQ; i += kBlock) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+    for (int i = threadIdx.x; i < NQ; i += kBlock) tw[i] = wf[i];
+    __syncthreads();
+    const int64_t n_int = n_e * NQ;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int branch = 0;
+    if (k < n_int) {
+        const int64_t e = k / NQ;
+        const int q = (int)(k - e * NQ);
+        double x[NP], y[NP], ux[NP], uy[NP], d1[NP], d2[NP], w;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            const int64_t nd = elem[(int64_t)a * n_e + e];
+            const double2 c = *reinterpret_cast<const double2*>(xy + 2 * nd);
+            const double2 u = *reinterpret_cast<const double2*>(U + 2 * nd);
+            x[a] = c.x; y[a] = c.y; ux[a] = u.x; uy[a] = u.y;
+        }
+        geometry_at_q<NP>(t1, t2, tw[q], q, NQ, x, y, d1, d2, w);
+        double ev[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {                   // DP:1043
+            ev[0] += d1[a] * ux[a]; ev[1] += d2[a] * uy[a]; ev[2] += d2[a] * ux[a] + d1[a] * uy[a];
+        }
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
+        double s[4], d[6];
+        branch = dp_return_map(ev, e0.v, p, shear[k], bulk[k], eta[k], cc[k], accept != 0, s, d);
+        store_point(k, n_int, s, d, branch, S, DS, indp);
+        if (Eout) { Eout[k] = ev[0]; Eout[n_int + k] = ev[1]; Eout[2 * n_int + k] = ev[2]; }
+        if (accept && ep && branch) { ep[k] = p[0]; ep[n_int + k] = p[1]; ep[2 * n_int + k] = p[2]; ep[3 * n_int + k] = p[3]; }
+    }
+    count_branches(branch, nullptr, blk_counts);
+}
+
+template <int NP, int NQ, int TPB>
+__global__ void __launch_bounds__(TPB)
+node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
+                const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
+                const int32_t* __restrict__ ncol, const int32_t* __restrict__ wg_elist,
+                const int32_t* __restrict__ elem, const double* __restrict__ xy,
+                const double* __restrict__ dh1, const double* __restrict__ dh2, const double* __restrict__ wf,
+                const double* __restrict__ DS, const double* __restrict__ S,
+                double* __restrict__ data, double* __restrict__ F,
+                int n_wg, int n_count_blocks, const uint2* __restrict__ blk_counts,
+                unsigned long long* __restrict__ counts_out) {
+    constexpr int NF = 9 + 2 * NP;                                    // fields per slot
+    extern __shared__ __attribute__((aligned(16))) double rec[];      // [NF][SL], tables, codes
+    const int SL = L * NQ;
+    double* t1 = rec + (int64_t)NF * SL;
+    double* t2 = t1 + NP * NQ;
+    double* tw = t2 + NP * NQ;
+    uint16_t* codes = reinterpret_cast<uint16_t*>(tw + NQ + (NQ & 1));
+    __shared__ int32_t t0_sh;
+    const int chunk = (n_wg + 7) >> 3;                                // XCD-aware tile order (see p1_node_lds_kernel)
+    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (counts_out != nullptr && blockIdx.x == gridDim.x - 1) sum_block_counts(n_count_blocks, blk_counts, counts_out);
+    if (wg >= n_wg) return;
+    const int64_t n_int = n_e * NQ;
+    const int64_t sb = (int64_t)wg * TPB + threadIdx.x;
+    const bool live = sb < n_blk;
+    // first-level loads: tables, the lane's block descriptors, codes
+    for (int i = threadIdx.x; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+    for (int i = threadIdx.x; i < NQ; i += TPB) tw[i] = wf[i];
+    const int32_t beg = live ? segptr[sb] : 0, end = live ? segptr[sb + 1] : 0;
+    const uint32_t m = live ? meta[sb] : 0u;
+    const int32_t fnode = (live && ((m >> 15) & 1u)) ? ncol[sb] : -1;
+    for (int i = threadIdx.x; i < C; i += TPB) codes[i] = perm_l[(int64_t)wg * C + i];
+    if (threadIdx.x == 0) t0_sh = beg;
+    __syncthreads();                                                  // tables ready
+    // staging: one (element, q) slot per lane and pass
+    for (int i = threadIdx.x; i < SL; i += TPB) {
+        const int el = i / NQ, q = i - el * NQ;
+        const int64_t e = wg_elist[(int64_t)wg * L + el];
+        const int64_t k = e * NQ + q;
+        double x[NP], y[NP], d1[NP], d2[NP], w;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            const int64_t nd = elem[(int64_t)a * n_e + e];
+            const double2 c = *reinterpret_cast<const double2*>(xy + 2 * nd);
+            x[a] = c.x; y[a] = c.y;
+        }
+        double dv[6] = {0, 0, 0, 0, 0, 0}, sv[3] = {0, 0, 0};
+        if (DS) {
+            dv[0] = DS[k]; dv[1] = DS[n_int + k]; dv[2] = DS[2 * n_int + k];
+            dv[3] = DS[4 * n_int + k]; dv[4] = DS[5 * n_int + k]; dv[5] = DS[8 * n_int + k];
+        }
+        if (S) { sv[0] = S[k]; sv[1] = S[n_int + k]; sv[2] = S[2 * n_int + k]; }
+        geometry_at_q<NP>(t1, t2, tw[q], q, NQ, x, y, d1, d2, w);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) rec[f * SL + i] = w * dv[f];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) rec[(6 + f) * SL + i] = w * sv[f];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { rec[(9 + a) * SL + i] = d1[a]; rec[(9 + NP + a) * SL + i] = d2[a]; }
+    }
+    __syncthreads();
+    if (!live) return;
+    const int32_t t0 = t0_sh;
+    const bool want_f = fnode >= 0 && F != nullptr && S != nullptr;
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
+    for (int32_t t = beg; t < end; ++t) {
+        const unsigned code = codes[t - t0];
+        const int a = (code >> 4) & 15, b = code & 15;
+        const int s0 = (int)(code >> 8) * NQ;
+        for (int q = 0; q < NQ; ++q) {
+            const int sl = s0 + q;
+            const double a1 = rec[(9 + a) * SL + sl], a2 = rec[(9 + NP + a) * SL + sl];
+            if (DS) {
+                const double b1 = rec[(9 + b) * SL + sl], b2 = rec[(9 + NP + b) * SL + sl];
+                const double D00 = rec[sl], D01 = rec[SL + sl], D02 = rec[2 * SL + sl];
+                const double D11 = rec[3 * SL + sl], D12 = rec[4 * SL + sl], D22 = rec[5 * SL + sl];
+                const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
+                const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+                k00 += r00 * b1 + r02 * b2;
+                k01 += r01 * b2 + r02 * b1;
+                k10 += r10 * b1 + r12 * b2;
+                k11 += r11 * b2 + r12 * b1;
+            }
+            if (want_f) {
+                f0 += a1 * rec[6 * SL + sl] + a2 * rec[8 * SL + sl];
+                f1 += a2 * rec[7 * SL + sl] + a1 * rec[8 * SL + sl];
+            }
+        }
+    }
+    if (data) {
+        const int64_t s = m & 0x7fffu, deg = m >> 16;
+        const int64_t pos0 = 4 * sb - 2 * s;
+        *reinterpret_cast<double2*>(data + pos0) = make_double2(k00, k01);
+        *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(k10, k11);
+    }
+    if (want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)fnode) = make_double2(f0, f1);
+}
+
 // Interface exchange helpers (multi-GPU): pack the rank's interface DOFs into the all-reduce buffer
 // (slots owned by other ranks are written as zeros, so no separate memset) and unpack the sums.
 __global__ void __launch_bounds__(kBlock)

@@ -156,6 +156,20 @@ def test_p1_routes_agree_and_match_reference(fep, p1_route):
     test_hot_path_mid_size_vs_oracle(fep, 'P1', 60)
 
 
+@pytest.fixture(params=['node', 'coo'])
+def gen_route(request, monkeypatch):
+    """P2 / Q1 / Q2 have two routes: node route (default) and the COO route (also what P4 uses)."""
+    monkeypatch.setenv('FEP_GEN_PATH', request.param)
+    return request.param
+
+
+@pytest.mark.parametrize('t,N', [('P2', 24), ('Q1', 40), ('Q2', 20)])
+def test_generic_routes_agree_and_match_reference(fep, gen_route, t, N):
+    test_hot_path_vs_reference_golden(fep, t, True)
+    test_hot_path_vs_reference_golden(fep, t, False)
+    test_hot_path_mid_size_vs_oracle(fep, t, N)
+
+
 @pytest.mark.parametrize('t', ELS)
 @pytest.mark.parametrize('accept', [False, True])
 def test_hot_path_vs_reference_golden(fep, t, accept):
