@@ -47,7 +47,8 @@ struct fep_ctx {
     double *geo = nullptr, *xy = nullptr;               // xy: interleaved (x,y) per node
     P1Tab p1tab{};
     int32_t *perm2 = nullptr, *ncol = nullptr;
-    int32_t *wg_eptr = nullptr, *wg_elist = nullptr;   // LDS-staged variant: per-workgroup element lists
+    int32_t *wg_eptr = nullptr, *wg_elist = nullptr, *wg_rng = nullptr;   // wg_rng: <= 8 (start, cum) runs per tile
+    bool p1_rng = false;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
     int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
     bool gn = false;                                    // node route for P2 / Q1 / Q2 (point_kernel + node_lds_kernel)
@@ -362,7 +363,7 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
-                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->perm_l, c->xy};
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -487,6 +488,25 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                 }
                 CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
                 CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
+                // run-length form of the lists: (start, cumulative count) x 8 per tile, if every list fits
+                std::vector<int32_t> rng((size_t)n_wg * 16);
+                bool fits = !(pth && std::strcmp(pth, "node_list") == 0);
+                for (int64_t g = 0; g < n_wg && fits; ++g) {
+                    const std::vector<int32_t>& l = lists[g];
+                    int nr = 0, cum = 0;
+                    int32_t* d = rng.data() + g * 16;
+                    for (size_t i = 0; i < l.size();) {
+                        size_t j = i + 1;
+                        while (j < l.size() && l[j] == l[j - 1] + 1) ++j;
+                        if (nr == 8) { fits = false; break; }
+                        cum += (int)(j - i);
+                        d[2 * nr] = l[i]; d[2 * nr + 1] = cum;
+                        ++nr; i = j;
+                    }
+                    for (; nr < 8; ++nr) { d[2 * nr] = l.empty() ? 0 : l[0]; d[2 * nr + 1] = cum; }
+                }
+                c->p1_rng = fits;
+                if (fits) CK(upload(&c->wg_rng, rng.data(), (int64_t)rng.size()));
             }
         }
         CK(dmalloc(&c->geo, 8 * n_e));
@@ -713,18 +733,25 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
             const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
             const int n_wg = (int)grid_for(c->n_blk, c->tile);
             const int chunk = (n_wg + 7) / 8;
-#define NODE_LDS(TPB)                                                                                                    \
+#define NODE_LDS2(TPB, RNG, EPT)                                                                                         \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB>,                                     \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB, RNG, EPT>,                           \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB>), dim3(8 * chunk), dim3(TPB), lds, st, c->n_blk, c->n_e,      \
-                           c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist, c->geo,              \
-                           k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks,           \
-                           c->blk_counts, counts_d, (long long*)nullptr);                                               \
+        hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB, RNG, EPT>), dim3(8 * chunk), dim3(TPB), lds, st, c->n_blk,    \
+                           c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,              \
+                           (const int4*)c->wg_rng, c->geo, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out,    \
+                           n_wg, c->n_count_blocks, c->blk_counts, counts_d, (long long*)nullptr);                       \
+    } while (0)
+#define NODE_LDS(TPB)                                                                                                    \
+    do {                                                                                                                 \
+        const bool one = c->lds_L <= TPB;                                                                                \
+        if (c->p1_rng) { if (one) NODE_LDS2(TPB, true, 1); else NODE_LDS2(TPB, true, 2); }                               \
+        else { if (one) NODE_LDS2(TPB, false, 1); else NODE_LDS2(TPB, false, 2); }                                       \
     } while (0)
             if (c->tile == 128) NODE_LDS(128); else if (c->tile == 512) NODE_LDS(512); else NODE_LDS(256);
 #undef NODE_LDS
+#undef NODE_LDS2
             if (counts_done) *counts_done = counts_d != nullptr;
         } else {
             hipLaunchKernelGGL(p1_node_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
@@ -969,7 +996,7 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
                                         double* f_out_d, long long* stamps_h, int64_t cap, int* n_wg_out) {
     if (!c || !c->p1_node || !c->p1_lds || !ds_d || !s_d || !k_data_d || !f_out_d || !stamps_h) return FEP_EINVAL;
     FEP_TRY(set_device(c->device));
-    if (c->tile != 256) return FEP_EINVAL;
+    if (c->tile != 256 || !c->p1_rng || c->lds_L > 256) return FEP_EINVAL;
     const int n_wg = (int)grid_for(c->n_blk, kBlock);
     if (n_wg_out) *n_wg_out = n_wg;
     if (cap < (int64_t)n_wg * 8) return FEP_EINVAL;
@@ -978,9 +1005,9 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
     const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
     const int chunk = (n_wg + 7) / 8;
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((p1_node_lds_kernel<true, 256>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
+        hipLaunchKernelGGL((p1_node_lds_kernel<true, 256, true, 1>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
                            c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,
-                           c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0, (const uint2*)nullptr,
+                           (const int4*)c->wg_rng, c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0, (const uint2*)nullptr,
                            (unsigned long long*)nullptr, st.as<long long>());
         HIP_TRY(hipGetLastError());
     }

@@ -535,12 +535,17 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 //   perm_l[wg*C + k]     gather codes (local element index << 4) | a << 2 | b   (uint16), padded to C
 //   LDS: rec[15][L] doubles, L = max list length, then the workgroup's gather codes (uint16)
 // ---------------------------------------------------------------------------------------
-template <bool DIAG, int TPB>
+// RNG = true: the tile's sorted element list is given as <= 8 runs of consecutive ids, 16 ints per tile
+// (start_r, cumulative count_r), fetched with scalar loads; the operand loads then depend on no vector
+// load at all, which takes one memory round trip out of every workgroup's critical path.  Chosen by the
+// host whenever every tile's list compresses into 8 runs (any mesh numbered with locality).
+template <bool DIAG, int TPB, bool RNG, int EPT>
 __global__ void __launch_bounds__(TPB)
 p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
                    const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
                    const int32_t* __restrict__ ncol,
-                   const int32_t* __restrict__ wg_elist, const double* __restrict__ geo,
+                   const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
+                   const double* __restrict__ geo,
                    const double* __restrict__ DS, const double* __restrict__ S,
                    double* __restrict__ data, double* __restrict__ F,
                    int n_wg, int n_count_blocks, const uint2* __restrict__ blk_counts,
@@ -563,65 +568,80 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // follow as soon as the list entries land.
     const int64_t sb = (int64_t)wg * TPB + threadIdx.x;
     const bool live = sb < n_blk;
-    constexpr int EPT = 2;                              // staged elements per lane (host guarantees L <= EPT*TPB)
-    constexpr int CPT = 4;                              // gather codes per lane      (host guarantees C <= CPT*TPB)
-    const int ecnt = L, ncodes = C;
+    constexpr int CPT = 4;                              // gather codes per lane (host guarantees C <= CPT*TPB)
+    // (1) element ids of the lane's staging slots
     int64_t el[EPT];
+    if (RNG) {
+        const int4* d = rng + (int64_t)wg * 4;          // uniform address: scalar loads
+        const int4 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+        const int st[8] = {d0.x, d0.z, d1.x, d1.z, d2.x, d2.z, d3.x, d3.z};
+        const int cu[8] = {d0.y, d0.w, d1.y, d1.w, d2.y, d2.w, d3.y, d3.w};
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            int e = st[0] + i;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) e = i >= cu[k - 1] ? st[k] + (i - cu[k - 1]) : e;
+            el[r] = i < cu[7] ? e : st[0];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            el[r] = wg_elist[(int64_t)wg * L + (i < L ? i : 0)];
+        }
+    }
+    if (DIAG) { st1 = (long long)__builtin_amdgcn_s_memtime(); }
+    // (2) operand loads: every lane loads (slots past the list repeat a valid element), no branch
+    double2 g0[EPT], g1[EPT], g2[EPT], g3[EPT];        // 64-byte geometry record (4 x 16-byte loads; the SoA dphi
+    double dv[EPT][6], sv[EPT][3];                      // arrays as 7 x 8-byte loads measured 5-10 us slower)
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
-        const int i = r * TPB + (int)threadIdx.x;
-        el[r] = wg_elist[(int64_t)wg * L + (i < L ? i : 0)];
+        const int64_t e = el[r];
+        const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
+        g0[r] = g[0]; g1[r] = g[1]; g2[r] = g[2]; g3[r] = g[3];
+        if (DS) {
+            dv[r][0] = DS[e]; dv[r][1] = DS[n_e + e]; dv[r][2] = DS[2 * n_e + e];
+            dv[r][3] = DS[4 * n_e + e]; dv[r][4] = DS[5 * n_e + e]; dv[r][5] = DS[8 * n_e + e];
+        }
+        if (S) { sv[r][0] = S[e]; sv[r][1] = S[n_e + e]; sv[r][2] = S[2 * n_e + e]; }
     }
+    if (DIAG) { st2 = (long long)__builtin_amdgcn_s_memtime(); }
+    // (3) the lane's block descriptors and the tile's gather codes: independent of (1)-(2), consumed last
     const int32_t beg = live ? segptr[sb] : 0, end = live ? segptr[sb + 1] : 0;
     const uint32_t m = live ? meta[sb] : 0u;
-    const int32_t fnode = (live && ((m >> 15) & 1u)) ? ncol[sb] : -1;
+    const int32_t ncol_sb = live ? ncol[sb] : -1;
     uint16_t cd[CPT];
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
         cd[r] = perm_l[(int64_t)wg * C + (i < C ? i : 0)];
     }
-    __shared__ int32_t t0_sh;
-    if (threadIdx.x == 0) t0_sh = beg;                  // first code of the tile (read after the barrier)
-    if (DIAG) { st1 = (long long)__builtin_amdgcn_s_memtime(); }
+    // (4) operands -> LDS
     uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
-        if (i < ecnt) {
-            const int64_t e = el[r];
-            if (DIAG && r == 0) { st2 = (long long)__builtin_amdgcn_s_memtime(); }
-            const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
-            const double2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-            double dv[6], sv[3];
-            if (DS) {
-                dv[0] = DS[e]; dv[1] = DS[n_e + e]; dv[2] = DS[2 * n_e + e];
-                dv[3] = DS[4 * n_e + e]; dv[4] = DS[5 * n_e + e]; dv[5] = DS[8 * n_e + e];
-            }
-            if (S) { sv[0] = S[e]; sv[1] = S[n_e + e]; sv[2] = S[2 * n_e + e]; }
-            if (r == 0) {                                 // codes -> LDS while the operands are in flight
-#pragma unroll
-                for (int q = 0; q < CPT; ++q) {
-                    const int ci = q * TPB + (int)threadIdx.x;
-                    if (ci < ncodes) codes[ci] = cd[q];
-                }
-            }
-            const double w = g3.x;
-            rec[9 * L + i] = g0.x;  rec[10 * L + i] = g0.y; rec[11 * L + i] = g1.x;     // d1[0..2]
-            rec[12 * L + i] = g1.y; rec[13 * L + i] = g2.x; rec[14 * L + i] = g2.y;     // d2[0..2]
+        if (i < L) {
+            const double w = g3[r].x;
+            rec[9 * L + i] = g0[r].x;  rec[10 * L + i] = g0[r].y; rec[11 * L + i] = g1[r].x;     // d1[0..2]
+            rec[12 * L + i] = g1[r].y; rec[13 * L + i] = g2[r].x; rec[14 * L + i] = g2[r].y;     // d2[0..2]
             if (DS) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) rec[k * L + i] = w * dv[k];
+                for (int k = 0; k < 6; ++k) rec[k * L + i] = w * dv[r][k];
             }
-            if (S) { rec[6 * L + i] = w * sv[0]; rec[7 * L + i] = w * sv[1]; rec[8 * L + i] = w * sv[2]; }
-        } else if (r == 0) {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                const int ci = q * TPB + (int)threadIdx.x;
-                if (ci < ncodes) codes[ci] = cd[q];
-            }
+            if (S) { rec[6 * L + i] = w * sv[r][0]; rec[7 * L + i] = w * sv[r][1]; rec[8 * L + i] = w * sv[r][2]; }
         }
     }
+    // (5) codes -> LDS, first code of the tile
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int ci = q * TPB + (int)threadIdx.x;
+        if (ci < C) codes[ci] = cd[q];
+    }
+    __shared__ int32_t t0_sh;
+    if (threadIdx.x == 0) t0_sh = beg;
+    const int32_t fnode = ((m >> 15) & 1u) ? ncol_sb : -1;
     if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st3 = (long long)__builtin_amdgcn_s_memtime(); }   // this wave's staging done
     __syncthreads();
     if (DIAG) st4 = (long long)__builtin_amdgcn_s_memtime();                                       // barrier released
