@@ -120,15 +120,33 @@ def main():
     DS = torch.empty((9, n_int), **f64)
     indp = torch.empty(n_int, dtype=torch.uint8, device=dev)
     Kd = torch.empty(ctx.nnz, **f64)
-    F = torch.empty(ctx.n_dof, **f64)
+    Fb = [torch.empty(ctx.n_dof, **f64) for _ in range(2 if world > 1 else 1)]
+    F = Fb[0]
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # N > 1: the interface all-reduce of pass i runs on a second stream under pass i+1's kernels (the force
+    # vector is double-buffered; a pass only waits for the exchange that last used its buffer)
+    main = torch.cuda.current_stream()
+    comm = torch.cuda.Stream() if world > 1 else None
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_ready = [torch.cuda.Event() for _ in range(2)]
+    state = {'i': 0}
+
     def step():
+        i = state['i'] & 1
+        state['i'] += 1
+        Fi = Fb[i] if world > 1 else F
+        if world > 1 and state['i'] > 2:
+            main.wait_event(ev_done[i])
         ctx.step_dev(stream, U.data_ptr(), ep=Ep.data_ptr(), accept=False, s=S.data_ptr(), ds=DS.data_ptr(),
-                     ind_p=indp.data_ptr(), k_data=Kd.data_ptr(), f_out=F.data_ptr(), counts=counts.data_ptr())
+                     ind_p=indp.data_ptr(), k_data=Kd.data_ptr(), f_out=Fi.data_ptr(), counts=counts.data_ptr())
         if world > 1:
-            sh.exchange_force_(F)
+            ev_ready[i].record(main)
+            comm.wait_event(ev_ready[i])
+            with torch.cuda.stream(comm):
+                sh.exchange_force_(Fi)
+                ev_done[i].record(comm)
 
     def barrier():
         if world > 1:

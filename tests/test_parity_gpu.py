@@ -392,3 +392,95 @@ def test_error_codes(fep):
     ctx = fep.MeshContext(np.array([[0], [1], [2]]), coord)
     with pytest.raises(fep.FepError):                     # materials not set -> FEP_ESTATE
         ctx.step(np.zeros(6))
+
+
+# ---- P4 (15 nodes, 12 points; TSX only) and ragged sizes ---------------------------------------------
+def test_p4_hot_path_vs_oracle_on_tsx_mesh(fep):
+    g = load_golden('tsx')
+    coord, elem = g['p4_coord'], g['p4_elem']
+    d1, d2, wf = tables('tsx', 'P4')
+    n_int = elem.shape[1] * 12
+    G = 60000 / (2 * (1 + 0.2)) * np.ones(n_int)
+    Kb = 60000 / (3 * (1 - 2 * 0.2)) * np.ones(n_int)
+    fr = 49 * np.pi / 180
+    eta = 3 * np.tan(fr) / np.sqrt(9 + 12 * np.tan(fr) ** 2) * np.ones(n_int)
+    c = 3 * 18.7 / np.sqrt(9 + 12 * np.tan(fr) ** 2) * np.ones(n_int)
+    rng = np.random.default_rng(8)
+    x, y = coord
+    U = np.array([4e-4 * x + 1e-4 * y, -6e-4 * y]) + rng.normal(0, 2e-5, size=coord.shape)
+    e0 = g['init_strain']
+    ctx = fep.MeshContext(elem, coord, d1, d2, wf)
+    ctx.set_materials(G, Kb, eta, c)
+    ep = np.zeros((4, n_int))
+    r = ctx.step(U, ep, e0=e0, apply_plastic_strain=True, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, G, Kb, d1, d2, wf)
+    ep_o = np.zeros((4, n_int))
+    E, cp, K_t, F = orc.hot_path(U, ep_o, dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=G, bulk=Kb,
+                                                eta=eta, c=c), apply_plastic_strain=True, e0=e0, tsx=True)
+    assert cp['n_smooth'] > 0 and cp['n_smooth'] + cp['n_apex'] < n_int
+    assert (r['n_smooth'], r['n_apex']) == (cp['n_smooth'], cp['n_apex'])
+    assert np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['E'], E) <= 1e-12
+    assert relerr(r['s'], cp['s']) <= 1e-12 and relerr(r['ds'], cp['ds']) <= 1e-12 and relerr(ep, ep_o) <= 1e-12
+    assert np.abs((r['K'] - K_t).data).max() <= 1e-11 * np.abs(K_t.data).max()
+    assert relerr(r['F'], F) <= 1e-11
+
+
+@pytest.mark.parametrize('t,nx,ny', [('P1', 1, 1), ('P1', 3, 2), ('Q1', 1, 1), ('Q1', 5, 3), ('P2', 1, 1), ('P2', 3, 3), ('Q2', 2, 2)])
+def test_tiny_and_ragged_meshes(fep, t, nx, ny):
+    """Meshes far smaller than a workgroup tile, element counts that are not multiples of any block size."""
+    if t in ('P1', 'Q1'):
+        mesh = fep.rect_mesh(nx, ny, t, 2.0, 3.0)
+    else:
+        mesh = fep.square_mesh(nx, t, 2.0)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    d1, d2, wf = fep.element_tables(t)
+    n_int = elem.shape[1] * NQ[t]
+    sh, bu, eta, c = dp_materials(n_int)
+    rng = np.random.default_rng(nx * 7 + ny)
+    U = rng.normal(0, 3e-4, size=coord.shape)
+    ctx = fep.MeshContext(elem, coord, d1, d2, wf)
+    ctx.set_materials(sh, bu, eta, c)
+    r = ctx.step(U, None, want=('s', 'ds', 'ind_p', 'K', 'F'))
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)
+    E, cp, K_t, F = orc.hot_path(U, None, dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=sh, bulk=bu,
+                                               eta=eta, c=c))
+    assert np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['s'], cp['s']) <= TOL_PT and relerr(r['ds'], cp['ds']) <= TOL_PT
+    assert relerr(r['K'].toarray(), K_t.toarray()) <= TOL_K and relerr(r['F'], F) <= TOL_K
+
+
+def test_p2_one_million_points_divergence_stress(fep):
+    """BASELINE configs[4] in miniature on one GPU: P2, branches i.i.d. per point (worst-case divergence inside
+    a wave); sampled points against the oracle's map, global invariants on K and F."""
+    N = 270                                                   # 145 800 P2 elements, 1 020 600 points
+    mesh = fep.square_mesh(N, 'P2', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n_e = elem.shape[1]
+    n_int = n_e * 7
+    sh, bu, eta, c = dp_materials(n_int)
+    rng = np.random.default_rng(17)
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10), -1.2e-4 * y]) + rng.normal(0, 2.5e-6, size=coord.shape)
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh, bu, eta, c)
+    r = ctx.step(U, None, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    n_el = n_int - r['n_smooth'] - r['n_apex']
+    assert min(n_el, r['n_smooth'], r['n_apex']) > 0.1 * n_int          # all three branches heavily populated
+    # neighbouring points differ in branch most of the time (divergence really happens inside waves)
+    br = r['ind_p'].astype(np.int8) + (np.abs(r['ds']).sum(axis=0) == 0)
+    assert (np.diff(br[:100000]) != 0).mean() > 0.3
+    sel = rng.choice(n_int, 5000, replace=False)
+    o = orc.return_map(r['E'][:, sel], None, sh[sel], bu[sel], eta[sel], c[sel])
+    assert np.array_equal(o['ind_p'], r['ind_p'][sel])
+    assert relerr(r['s'][:, sel], o['s']) <= TOL_PT and relerr(r['ds'][:, sel], o['ds']) <= TOL_PT
+    K = r['K']
+    assert np.abs(K - K.T).data.max() <= 1e-12 * np.abs(K.data).max()
+    rigid = np.tile([0.0, 1.0], coord.shape[1])
+    assert np.abs(K @ rigid).max() <= 1e-9 * np.abs(K.data).max()
+    K2, F2 = ctx.assemble(r['ds'], r['s'])
+    assert np.array_equal(K2.data, K.data) and np.array_equal(F2, r['F'])
+    # sum of nodal forces = 0 for a self-equilibrated stress field integrated over the whole body (B^T s sums to zero
+    # against rigid translations)
+    assert abs(r['F'][0::2].sum()) <= 1e-9 * np.abs(r['F']).sum() and abs(r['F'][1::2].sum()) <= 1e-9 * np.abs(r['F']).sum()
+    ctx.close()
