@@ -22,11 +22,13 @@ from ._lib import FepError, lib, lib_path
 from .build import build
 from .sharding import Partition, ShardedContext, element_ranges
 from .newton import solve_strip_footing, solve_tsx_tunnel, transform
+from .midpoints import create_midpoints, create_midpoints_P2, create_midpoints_P4
 from . import plasticity2d_dp, tsx_tunnel, elasticity2d
 
 __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get_local_basis_volume',
            'element_tables', 'assemble_mesh', 'square_mesh', 'rect_mesh', 'Partition', 'ShardedContext', 'element_ranges', 'MeshContext', 'construct_constitutive_problem',
            'construct_constitutive_problem_tsx', 'get_elastic_stiffness_matrix', 'get_elastic_stiffness_matrix_el',
            'assemble_tangent', 'default_device', 'FepError', 'lib', 'lib_path', 'build',
-           'solve_strip_footing', 'solve_tsx_tunnel', 'transform',
+           'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'create_midpoints', 'create_midpoints_P2',
+           'create_midpoints_P4',
            'plasticity2d_dp', 'tsx_tunnel', 'elasticity2d']

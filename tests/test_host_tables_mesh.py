@@ -51,3 +51,30 @@ def test_survey_pins_n20(fep):
     assert m['elements'].shape == (3, 1002528) and m['coordinates'].shape == (2, 502681)
     m = fep.square_mesh(181, 'P1', 10)
     assert m['elements'].shape == (3, 65522)
+
+
+@pytest.mark.parametrize('t', ['P2', 'P4'])
+def test_midpoint_numbering_bit_exact_on_tunnel_mesh(fep, t):
+    """create_midpoints_P2 / _P4 (TSX:1354-1626) on the reference's own unstructured mesh (coord.csv / elem.csv):
+    identical ids, local order and coordinates as the reference generator."""
+    g = load_golden('tsx')
+    r = fep.tsx_tunnel.create_midpoints(fep.LagrangeElementType[t], g['coord'], g['elem'])
+    key = t.lower()
+    assert r['elem_ext'].dtype.kind == 'i' and np.array_equal(r['elem_ext'], g[f'{key}_elem'])
+    assert np.array_equal(r['coord_ext'], g[f'{key}_coord'])
+    assert r['coord_ext'].shape[1] == {'P2': 1839, 'P4': 7226}[t]
+    assert fep.create_midpoints('P1', g['coord'], g['elem']) is None            # TSX:1629-1633 quirk (C11)
+    # every new node is referenced, boundary edges are listed once
+    n0 = g['coord'].shape[1]
+    assert np.array_equal(np.unique(r['elem_ext'][3:]), np.arange(n0, r['coord_ext'].shape[1]))
+    assert r['surf'].shape[1] > 0
+
+
+def test_midpoints_structured_matches_p2_generator_geometry(fep):
+    """On a structured P1 square the generated P2 nodes are exactly the edge midpoints."""
+    m = fep.square_mesh(5, 'P1', 10)
+    r = fep.create_midpoints_P2(m['coordinates'], m['elements'])
+    el, co = r['elem_ext'], r['coord_ext']
+    for s, (a, b) in enumerate(((1, 2), (2, 0), (0, 1))):
+        assert np.array_equal(co[:, el[3 + s]], (co[:, el[a]] + co[:, el[b]]) / 2)
+    assert co.shape[1] == 36 + 85                                                # nodes + edges of a 5x5 cell square
