@@ -48,7 +48,9 @@ struct fep_ctx {
     P1Tab p1tab{};
     int32_t *perm2 = nullptr, *ncol = nullptr;
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr, *wg_rng = nullptr;   // wg_rng: <= 8 (start, cum) runs per tile
-    bool p1_rng = false;   // LDS-staged variant: per-workgroup element lists
+    bool p1_rng = false, p1_pk = false;
+    uint32_t* pk = nullptr;                             // packed block descriptors (beg_local | len | deg | slot | diag)
+    int32_t* tile_fnode0 = nullptr;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
     int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
     bool gn = false;                                    // node route for P2 / Q1 / Q2 (point_kernel + node_lds_kernel)
@@ -363,7 +365,7 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
-                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy};
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tile_fnode0};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -507,6 +509,33 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                 }
                 c->p1_rng = fits;
                 if (fits) CK(upload(&c->wg_rng, rng.data(), (int64_t)rng.size()));
+                // packed block descriptors, if every field fits its bit width
+                std::vector<uint32_t> pkv((size_t)c->n_blk);
+                std::vector<int32_t> fn0((size_t)n_wg, 0);
+                bool pk_ok = CP <= 2047 && !(pth && std::strcmp(pth, "node_unpacked") == 0);
+                for (int64_t g = 0; g < n_wg && pk_ok; ++g) {
+                    const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                    const int32_t t0 = S.segptr[b0];
+                    bool seen = false;
+                    int32_t prev = -1;
+                    for (int64_t b = b0; b < b1; ++b) {
+                        const uint32_t mt = S.meta[b];
+                        const uint32_t len = (uint32_t)(S.segptr[b + 1] - S.segptr[b]), deg = mt >> 16, slot = mt & 0x7fffu;
+                        const uint32_t diag = (mt >> 15) & 1u;
+                        if (len > 15 || deg > 255 || slot > 255) { pk_ok = false; break; }
+                        pkv[b] = (uint32_t)(S.segptr[b] - t0) | (len << 11) | (deg << 15) | (slot << 23) | (diag << 31);
+                        if (diag) {      // diagonal lanes of a tile must belong to consecutive nodes
+                            if (!seen) { fn0[g] = S.ncol[b]; seen = true; }
+                            else if (S.ncol[b] != prev + 1) { pk_ok = false; break; }
+                            prev = S.ncol[b];
+                        }
+                    }
+                }
+                c->p1_pk = pk_ok;
+                if (pk_ok) {
+                    CK(upload(&c->pk, pkv.data(), (int64_t)pkv.size()));
+                    CK(upload(&c->tile_fnode0, fn0.data(), (int64_t)fn0.size()));
+                }
             }
         }
         CK(dmalloc(&c->geo, 8 * n_e));
@@ -733,16 +762,18 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
             const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
             const int n_wg = (int)grid_for(c->n_blk, c->tile);
             const int chunk = (n_wg + 7) / 8;
-#define NODE_LDS2(TPB, RNG, EPT)                                                                                         \
+#define NODE_LDS3(TPB, RNG, EPT, PK)                                                                                     \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB, RNG, EPT>,                           \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB, RNG, EPT, PK>,                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB, RNG, EPT>), dim3(8 * chunk), dim3(TPB), lds, st, c->n_blk,    \
-                           c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,              \
-                           (const int4*)c->wg_rng, c->geo, k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out,    \
-                           n_wg, c->n_count_blocks, c->blk_counts, counts_d, (long long*)nullptr);                       \
+        hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB, RNG, EPT, PK>), dim3(8 * chunk), dim3(TPB), lds, st,          \
+                           c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,    \
+                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->geo, k_data ? ds : nullptr,                 \
+                           f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks, c->blk_counts, counts_d,         \
+                           (long long*)nullptr);                                                                         \
     } while (0)
+#define NODE_LDS2(TPB, RNG, EPT) do { if (c->p1_pk) NODE_LDS3(TPB, RNG, EPT, true); else NODE_LDS3(TPB, RNG, EPT, false); } while (0)
 #define NODE_LDS(TPB)                                                                                                    \
     do {                                                                                                                 \
         const bool one = c->lds_L <= TPB;                                                                                \
@@ -752,6 +783,7 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
             if (c->tile == 128) NODE_LDS(128); else if (c->tile == 512) NODE_LDS(512); else NODE_LDS(256);
 #undef NODE_LDS
 #undef NODE_LDS2
+#undef NODE_LDS3
             if (counts_done) *counts_done = counts_d != nullptr;
         } else {
             hipLaunchKernelGGL(p1_node_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
@@ -1005,9 +1037,10 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
     const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
     const int chunk = (n_wg + 7) / 8;
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((p1_node_lds_kernel<true, 256, true, 1>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
+        hipLaunchKernelGGL((p1_node_lds_kernel<true, 256, true, 1, false>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
                            c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,
-                           (const int4*)c->wg_rng, c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0, (const uint2*)nullptr,
+                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0,
+                           (const uint2*)nullptr,
                            (unsigned long long*)nullptr, st.as<long long>());
         HIP_TRY(hipGetLastError());
     }

@@ -539,12 +539,16 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 // (start_r, cumulative count_r), fetched with scalar loads; the operand loads then depend on no vector
 // load at all, which takes one memory round trip out of every workgroup's critical path.  Chosen by the
 // host whenever every tile's list compresses into 8 runs (any mesh numbered with locality).
-template <bool DIAG, int TPB, bool RNG, int EPT>
+// PK = true: the lane's block descriptor is ONE packed word (pk: beg_local:11 | len:4 | deg:8 | slot:8 | diag:1)
+// instead of segptr x2 + meta + ncol (16 -> 4 bytes per block = 42 MB per launch at 1 M elements); the node that a
+// diagonal lane sums the force for is tile_fnode0[tile] + (number of diagonal lanes before it in the tile).
+template <bool DIAG, int TPB, bool RNG, int EPT, bool PK>
 __global__ void __launch_bounds__(TPB)
 p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
                    const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
                    const int32_t* __restrict__ ncol,
                    const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
+                   const uint32_t* __restrict__ pk, const int32_t* __restrict__ tile_fnode0,
                    const double* __restrict__ geo,
                    const double* __restrict__ DS, const double* __restrict__ S,
                    double* __restrict__ data, double* __restrict__ F,
@@ -608,9 +612,19 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     }
     if (DIAG) { st2 = (long long)__builtin_amdgcn_s_memtime(); }
     // (3) the lane's block descriptors and the tile's gather codes: independent of (1)-(2), consumed last
-    const int32_t beg = live ? segptr[sb] : 0, end = live ? segptr[sb + 1] : 0;
-    const uint32_t m = live ? meta[sb] : 0u;
-    const int32_t ncol_sb = live ? ncol[sb] : -1;
+    int32_t beg, end, ncol_sb = -1;
+    uint32_t m;
+    if (PK) {
+        const uint32_t w = live ? pk[sb] : 0u;
+        beg = (int32_t)(w & 2047u);
+        end = beg + (int32_t)((w >> 11) & 15u);
+        m = (((w >> 15) & 255u) << 16) | ((w >> 31) << 15) | ((w >> 23) & 255u);     // deg | diag | slot
+    } else {
+        beg = live ? segptr[sb] : 0;
+        end = live ? segptr[sb + 1] : 0;
+        m = live ? meta[sb] : 0u;
+        ncol_sb = live ? ncol[sb] : -1;
+    }
     uint16_t cd[CPT];
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
@@ -640,13 +654,29 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
         if (ci < C) codes[ci] = cd[q];
     }
     __shared__ int32_t t0_sh;
-    if (threadIdx.x == 0) t0_sh = beg;
-    const int32_t fnode = ((m >> 15) & 1u) ? ncol_sb : -1;
+    __shared__ int32_t wdiag[TPB / 64];
+    const bool is_diag = (m >> 15) & 1u;
+    unsigned long long dmask = 0;
+    if (PK) {
+        dmask = __ballot(is_diag);
+        if ((threadIdx.x & 63) == 0) wdiag[threadIdx.x >> 6] = __popcll(dmask);
+    } else if (threadIdx.x == 0) {
+        t0_sh = beg;
+    }
     if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st3 = (long long)__builtin_amdgcn_s_memtime(); }   // this wave's staging done
     __syncthreads();
     if (DIAG) st4 = (long long)__builtin_amdgcn_s_memtime();                                       // barrier released
     if (!live) return;
-    const int32_t t0 = t0_sh;
+    int32_t t0, fnode;
+    if (PK) {
+        t0 = 0;                                        // pk holds tile-local code offsets
+        int before = __popcll(dmask & ((1ull << (threadIdx.x & 63)) - 1ull));
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wdiag[w];
+        fnode = is_diag ? tile_fnode0[wg] + before : -1;
+    } else {
+        t0 = t0_sh;
+        fnode = is_diag ? ncol_sb : -1;
+    }
     const bool want_f = fnode >= 0 && F != nullptr && S != nullptr;
     double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
     for (int32_t t = beg; t < end; ++t) {

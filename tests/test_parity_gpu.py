@@ -143,7 +143,7 @@ def test_elastic_setup_vs_reference_golden(fep, t):
 
 
 # ---- a1..a5 ---------------------------------------------------------------------------
-@pytest.fixture(params=['node', 'node_list', 'node_direct', 'coo'])
+@pytest.fixture(params=['node', 'node_unpacked', 'node_list', 'node_direct', 'coo'])
 def p1_route(request, monkeypatch):
     """P1 has two routes: the node-centric fast path (default) and the generic COO route."""
     monkeypatch.setenv('FEP_P1_PATH', request.param)
