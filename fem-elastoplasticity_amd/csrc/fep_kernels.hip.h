@@ -572,7 +572,8 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // follow as soon as the list entries land.
     const int64_t sb = (int64_t)wg * TPB + threadIdx.x;
     const bool live = sb < n_blk;
-    constexpr int CPT = 4;                              // gather codes per lane (host guarantees C <= CPT*TPB)
+    constexpr int CWPT = 2;                             // 32-bit words of gather codes per lane (2 codes each;
+                                                        // host guarantees C <= 2*CWPT*TPB and C even)
     // (1) element ids of the lane's staging slots
     int64_t el[EPT];
     if (RNG) {
@@ -625,11 +626,13 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
         m = live ? meta[sb] : 0u;
         ncol_sb = live ? ncol[sb] : -1;
     }
-    uint16_t cd[CPT];
+    const int CW = C >> 1;
+    const uint32_t* codes_w = reinterpret_cast<const uint32_t*>(perm_l) + (int64_t)wg * CW;
+    uint32_t cd[CWPT];
 #pragma unroll
-    for (int r = 0; r < CPT; ++r) {
+    for (int r = 0; r < CWPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
-        cd[r] = perm_l[(int64_t)wg * C + (i < C ? i : 0)];
+        cd[r] = codes_w[i < CW ? i : 0];
     }
     // (4) operands -> LDS
     uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
@@ -648,10 +651,11 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
         }
     }
     // (5) codes -> LDS, first code of the tile
+    uint32_t* codes32 = reinterpret_cast<uint32_t*>(rec + 15 * L);
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) {
+    for (int q = 0; q < CWPT; ++q) {
         const int ci = q * TPB + (int)threadIdx.x;
-        if (ci < C) codes[ci] = cd[q];
+        if (ci < CW) codes32[ci] = cd[q];
     }
     __shared__ int32_t t0_sh;
     __shared__ int32_t wdiag[TPB / 64];
