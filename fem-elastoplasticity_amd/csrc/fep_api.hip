@@ -50,7 +50,8 @@ struct fep_ctx {
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr, *wg_rng = nullptr;   // wg_rng: <= 8 (start, cum) runs per tile
     bool p1_rng = false, p1_pk = false;
     uint32_t* pk = nullptr;                             // packed block descriptors (beg_local | len | deg | slot | diag)
-    int32_t* tile_fnode0 = nullptr;   // LDS-staged variant: per-workgroup element lists
+    int32_t *tile_fnode0 = nullptr, *tstart = nullptr;  // tstart: first block of every tile (tiles hold whole nodes)
+    int n_wg_p1 = 0;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
     int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
     bool gn = false;                                    // node route for P2 / Q1 / Q2 (point_kernel + node_lds_kernel)
@@ -365,7 +366,7 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
-                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tile_fnode0};
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tile_fnode0, c->tstart};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -437,7 +438,17 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         {   // per-workgroup (`tile` consecutive blocks) sorted unique element lists + local gather codes
             if (const char* tv = std::getenv("FEP_NODE_TILE")) { const int t = std::atoi(tv); if (t == 128 || t == 256 || t == 512) c->tile = t; }
             const int64_t TILE = c->tile;
-            const int64_t n_wg = (c->n_blk + TILE - 1) / TILE;
+            // tiles = runs of WHOLE nodes with at most TILE blocks (a node's blocks are consecutive ids)
+            std::vector<int32_t> tstart{0};
+            for (int64_t n = 0, cur = 0; n < n_n; ++n) {
+                const int64_t d = S.nptr[n + 1] - S.nptr[n];
+                if (d > TILE) { r = FEP_ERANGE; break; }
+                if (cur + d > TILE) { tstart.push_back(S.nptr[n]); cur = 0; }
+                cur += d;
+            }
+            tstart.push_back((int32_t)c->n_blk);
+            const int64_t n_wg = (int64_t)tstart.size() - 1;
+            c->n_wg_p1 = (int)n_wg;
             std::vector<int32_t> eptr(n_wg + 1, 0);
             std::vector<std::vector<int32_t>> lists(n_wg);
             std::vector<uint16_t> perm_l(perm2.size());
@@ -446,7 +457,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             for (int w = 0; w < nthreads; ++w)
                 th.emplace_back([&, w]() {
                     for (int64_t g = n_wg * w / nthreads; g < n_wg * (w + 1) / nthreads; ++g) {
-                        const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                        const int64_t b0 = tstart[g], b1 = tstart[g + 1];
                         const int32_t t0 = S.segptr[b0], t1 = S.segptr[b1];
                         std::vector<int32_t>& l = lists[g];
                         l.reserve(t1 - t0);
@@ -464,7 +475,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             for (int64_t g = 0; g < n_wg; ++g) {
                 eptr[g + 1] = eptr[g] + (int32_t)lists[g].size();
                 lmax = std::max(lmax, lists[g].size());
-                const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                const int64_t b0 = tstart[g], b1 = tstart[g + 1];
                 cmax = std::max(cmax, (size_t)(S.segptr[b1] - S.segptr[b0]));
             }
             c->lds_C = (int)((cmax + 7) & ~(size_t)7);
@@ -485,9 +496,10 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                 for (int64_t g = 0; g < n_wg; ++g) {
                     std::fill(elist_pad.begin() + g * LP, elist_pad.begin() + (g + 1) * LP, lists[g].empty() ? 0 : lists[g][0]);
                     std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * LP);
-                    const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                    const int64_t b0 = tstart[g], b1 = tstart[g + 1];
                     std::copy(perm_l.begin() + S.segptr[b0], perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * CP);
                 }
+                CK(upload(&c->tstart, tstart.data(), (int64_t)tstart.size()));
                 CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
                 CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
                 // run-length form of the lists: (start, cumulative count) x 8 per tile, if every list fits
@@ -514,7 +526,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                 std::vector<int32_t> fn0((size_t)n_wg, 0);
                 bool pk_ok = CP <= 2047 && !(pth && std::strcmp(pth, "node_unpacked") == 0);
                 for (int64_t g = 0; g < n_wg && pk_ok; ++g) {
-                    const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
+                    const int64_t b0 = tstart[g], b1 = tstart[g + 1];
                     const int32_t t0 = S.segptr[b0];
                     bool seen = false;
                     int32_t prev = -1;
@@ -759,8 +771,10 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
     if (counts_done) *counts_done = false;
     if ((k_data && ds) || (f_out && s)) {
         if (c->p1_lds) {
-            const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
-            const int n_wg = (int)grid_for(c->n_blk, c->tile);
+            // operands + codes while gathering, then the same LDS holds the tile's output (4*TPB values + forces)
+            const size_t lds = std::max((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t),
+                                        (size_t)c->tile * 3 * sizeof(double2));
+            const int n_wg = c->n_wg_p1;
             const int chunk = (n_wg + 7) / 8;
 #define NODE_LDS3(TPB, RNG, EPT, PK)                                                                                     \
     do {                                                                                                                 \
@@ -769,7 +783,7 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
         hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB, RNG, EPT, PK>), dim3(8 * chunk), dim3(TPB), lds, st,          \
                            c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,    \
-                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->geo, k_data ? ds : nullptr,                 \
+                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->tstart, c->geo, k_data ? ds : nullptr,      \
                            f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks, c->blk_counts, counts_d,         \
                            (long long*)nullptr);                                                                         \
     } while (0)
@@ -1029,17 +1043,18 @@ extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const do
     if (!c || !c->p1_node || !c->p1_lds || !ds_d || !s_d || !k_data_d || !f_out_d || !stamps_h) return FEP_EINVAL;
     FEP_TRY(set_device(c->device));
     if (c->tile != 256 || !c->p1_rng || c->lds_L > 256) return FEP_EINVAL;
-    const int n_wg = (int)grid_for(c->n_blk, kBlock);
+    const int n_wg = c->n_wg_p1;
     if (n_wg_out) *n_wg_out = n_wg;
     if (cap < (int64_t)n_wg * 8) return FEP_EINVAL;
     DevBuf st;
     FEP_TRY(st.alloc((int64_t)n_wg * 8 * sizeof(long long)));
-    const size_t lds = (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t);
+    const size_t lds = std::max((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t),
+                                (size_t)c->tile * 3 * sizeof(double2));
     const int chunk = (n_wg + 7) / 8;
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL((p1_node_lds_kernel<true, 256, true, 1, false>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
                            c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,
-                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0,
+                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->tstart, c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0,
                            (const uint2*)nullptr,
                            (unsigned long long*)nullptr, st.as<long long>());
         HIP_TRY(hipGetLastError());

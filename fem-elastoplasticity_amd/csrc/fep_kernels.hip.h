@@ -549,6 +549,7 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
                    const int32_t* __restrict__ ncol,
                    const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
                    const uint32_t* __restrict__ pk, const int32_t* __restrict__ tile_fnode0,
+                   const int32_t* __restrict__ tstart,
                    const double* __restrict__ geo,
                    const double* __restrict__ DS, const double* __restrict__ S,
                    double* __restrict__ data, double* __restrict__ F,
@@ -570,8 +571,12 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // L entries, gather codes: C entries, unused slots repeat a valid entry), so all first-level
     // addresses are functions of (tile, lane) and go out together at kernel entry; the operand loads
     // follow as soon as the list entries land.
-    const int64_t sb = (int64_t)wg * TPB + threadIdx.x;
-    const bool live = sb < n_blk;
+    // tiles hold whole nodes: blocks [tstart[wg], tstart[wg+1]), at most TPB of them, so the CSR values and the
+    // force entries a tile produces form ONE contiguous range each
+    const int64_t sb0 = tstart[wg];
+    const int nb = tstart[wg + 1] - (int)sb0;
+    const int64_t sb = sb0 + threadIdx.x;
+    const bool live = (int)threadIdx.x < nb;
     constexpr int CWPT = 2;                             // 32-bit words of gather codes per lane (2 codes each;
                                                         // host guarantees C <= 2*CWPT*TPB and C even)
     // (1) element ids of the lane's staging slots
@@ -670,46 +675,67 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st3 = (long long)__builtin_amdgcn_s_memtime(); }   // this wave's staging done
     __syncthreads();
     if (DIAG) st4 = (long long)__builtin_amdgcn_s_memtime();                                       // barrier released
-    if (!live) return;
-    int32_t t0, fnode;
+    int32_t t0, fnode_k = -1;
     if (PK) {
         t0 = 0;                                        // pk holds tile-local code offsets
         int before = __popcll(dmask & ((1ull << (threadIdx.x & 63)) - 1ull));
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wdiag[w];
-        fnode = is_diag ? tile_fnode0[wg] + before : -1;
+        fnode_k = is_diag ? before : -1;               // k-th node of the tile
     } else {
         t0 = t0_sh;
-        fnode = is_diag ? ncol_sb : -1;
     }
-    const bool want_f = fnode >= 0 && F != nullptr && S != nullptr;
+    const bool want_f = live && is_diag && F != nullptr && S != nullptr;
     double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
-    for (int32_t t = beg; t < end; ++t) {
-        const unsigned code = codes[t - t0];
-        const int i = code >> 4, a = (code >> 2) & 3, b = code & 3;
-        const double a1 = rec[(9 + a) * L + i], a2 = rec[(12 + a) * L + i];
-        const double b1 = rec[(9 + b) * L + i], b2 = rec[(12 + b) * L + i];
-        if (DS) {
-            const double D00 = rec[i], D01 = rec[L + i], D02 = rec[2 * L + i];
-            const double D11 = rec[3 * L + i], D12 = rec[4 * L + i], D22 = rec[5 * L + i];
-            const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
-            const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
-            k00 += r00 * b1 + r02 * b2;
-            k01 += r01 * b2 + r02 * b1;
-            k10 += r10 * b1 + r12 * b2;
-            k11 += r11 * b2 + r12 * b1;
-        }
-        if (want_f) {
-            f0 += a1 * rec[6 * L + i] + a2 * rec[8 * L + i];
-            f1 += a2 * rec[7 * L + i] + a1 * rec[8 * L + i];
+    if (live) {
+        for (int32_t t = beg; t < end; ++t) {
+            const unsigned code = codes[t - t0];
+            const int i = code >> 4, a = (code >> 2) & 3, b = code & 3;
+            const double a1 = rec[(9 + a) * L + i], a2 = rec[(12 + a) * L + i];
+            const double b1 = rec[(9 + b) * L + i], b2 = rec[(12 + b) * L + i];
+            if (DS) {
+                const double D00 = rec[i], D01 = rec[L + i], D02 = rec[2 * L + i];
+                const double D11 = rec[3 * L + i], D12 = rec[4 * L + i], D22 = rec[5 * L + i];
+                const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
+                const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+                k00 += r00 * b1 + r02 * b2;
+                k01 += r01 * b2 + r02 * b1;
+                k10 += r10 * b1 + r12 * b2;
+                k11 += r11 * b2 + r12 * b1;
+            }
+            if (want_f) {
+                f0 += a1 * rec[6 * L + i] + a2 * rec[8 * L + i];
+                f1 += a2 * rec[7 * L + i] + a1 * rec[8 * L + i];
+            }
         }
     }
+    // Results leave through LDS: a lane's two 16-byte pieces belong to two different CSR rows, so direct stores
+    // write every 128-byte line in two half-filled passes (measured ~14 us per launch); staged, the tile's
+    // 4*nb values (and its nodes' forces) go out as full, consecutive lines.
+    __syncthreads();                                   // every lane is done reading the staged operands
+    double2* out2 = reinterpret_cast<double2*>(rec);
+    if (live && data) {
+        const int64_t sl = m & 0x7fffu, deg = m >> 16;
+        const int rel = 4 * (int)threadIdx.x - 2 * (int)sl;      // = CSR position - 4*sb0, always even
+        out2[rel >> 1] = make_double2(k00, k01);
+        out2[(rel >> 1) + (int)deg] = make_double2(k10, k11);
+    }
+    double2* fo2 = out2 + 2 * TPB;
+    if (PK) { if (want_f) fo2[fnode_k] = make_double2(f0, f1); }
+    __syncthreads();
     if (data) {
-        const int64_t s = m & 0x7fffu, deg = m >> 16;
-        const int64_t pos0 = 4 * sb - 2 * s;
-        *reinterpret_cast<double2*>(data + pos0) = make_double2(k00, k01);
-        *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(k10, k11);
+        double2* dst = reinterpret_cast<double2*>(data + 4 * sb0);
+        for (int i = threadIdx.x; i < 2 * nb; i += TPB) dst[i] = out2[i];
     }
-    if (want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)fnode) = make_double2(f0, f1);
+    if (F != nullptr && S != nullptr) {
+        if (PK) {
+            int ndiag = 0;
+            for (int w = 0; w < TPB / 64; ++w) ndiag += wdiag[w];
+            double2* dstf = reinterpret_cast<double2*>(F + 2 * (int64_t)tile_fnode0[wg]);
+            if ((int)threadIdx.x < ndiag) dstf[threadIdx.x] = fo2[threadIdx.x];
+        } else if (want_f) {
+            *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol_sb) = make_double2(f0, f1);
+        }
+    }
     if (DIAG && threadIdx.x == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         long long* o = stamps + (int64_t)wg * 8;

@@ -28,7 +28,7 @@ F = torch.empty(ctx.n_dof, dtype=torch.float64, device=dev)
 ctx.step_dev(0, U.data_ptr(), s=S.data_ptr(), ds=DS.data_ptr(), k_data=Kd.data_ptr(), f_out=F.data_ptr())
 torch.cuda.synchronize()
 l = fep.lib()
-n_wg = (ctx.n_blk + 255) // 256
+n_wg = ctx.n_blk // 128 + 8          # upper bound; the library returns the real tile count
 st = np.zeros((n_wg, 8), dtype=np.int64)
 nw = C.c_int()
 fn = l.fep_debug_p1_node_stamps
@@ -36,6 +36,8 @@ fn.restype = C.c_int
 rc = fn(ctx.handle, C.c_void_p(DS.data_ptr()), C.c_void_p(S.data_ptr()), C.c_void_p(Kd.data_ptr()), C.c_void_p(F.data_ptr()),
         st.ctypes.data_as(C.c_void_p), C.c_int64(st.size), C.byref(nw))
 assert rc == 0, rc
+st = st[:nw.value]
+n_wg = nw.value
 d = np.diff(st[:, :6], axis=1)
 names = ['prologue loads (segptr/meta/codes)', 'eptr + list entry', 'element data -> LDS', 'barrier wait', 'gather+FMA+store']
 print(f'n_wg={n_wg}  staged elements per wg: mean {st[:,7].mean():.1f} max {st[:,7].max()}')
