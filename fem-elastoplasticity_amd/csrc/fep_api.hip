@@ -421,6 +421,16 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     CK(dmalloc(&c->shear, c->n_int)); CK(dmalloc(&c->bulk, c->n_int)); CK(dmalloc(&c->eta, c->n_int)); CK(dmalloc(&c->c, c->n_int));
     CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
     CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
+    // tiles of whole nodes with at most kBlock node-pair blocks (a node's blocks are consecutive ids): the CSR
+    // values a tile produces are one contiguous range
+    std::vector<int32_t> tstart_all{0};
+    for (int64_t n = 0, cur = 0; n < n_n; ++n) {
+        const int64_t d = S.nptr[n + 1] - S.nptr[n];
+        if (d > kBlock) { r = FEP_ERANGE; break; }
+        if (cur + d > kBlock) { tstart_all.push_back(S.nptr[n]); cur = 0; }
+        cur += d;
+    }
+    tstart_all.push_back((int32_t)c->n_blk);
     {   // P1 runs the node-centric fast path unless FEP_P1_PATH=coo asks for the generic COO route
         const char* pth = std::getenv("FEP_P1_PATH");
         c->p1_node = elem_type == FEP_P1 && !(pth && std::strcmp(pth, "coo") == 0);
@@ -626,6 +636,8 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     }
     if (!c->p1_node && !c->gn) {
         CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
+        CK(upload(&c->tstart, tstart_all.data(), (int64_t)tstart_all.size()));
+        c->n_wg_p1 = (int)tstart_all.size() - 1;
         CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
         CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
         CK(dmalloc(&c->Kc, 4 * c->n_contrib));
@@ -748,8 +760,8 @@ static int launch_counts(fep_ctx* c, hipStream_t st, unsigned long long* counts_
 static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_out) {
     FEP_TRY(prof_mark(c, st));
     if (k_data) {
-        hipLaunchKernelGGL(csr_reduce_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
-                           c->n_blk, c->segptr, c->perm, c->meta, c->Kc, k_data);
+        hipLaunchKernelGGL(csr_reduce_kernel, dim3(c->n_wg_p1), dim3(kBlock), 0, st,
+                           c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data);
         HIP_TRY(hipGetLastError());
     }
     FEP_TRY(prof_mark(c, st));

@@ -375,22 +375,35 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 //   CSR data: row 2n+i starts at 4*nptr[n] + i*2*deg, entry (slot s, comp j) at + 2s + j.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-csr_reduce_kernel(int64_t n_blk, const int32_t* __restrict__ segptr, const int32_t* __restrict__ perm,
-                  const uint32_t* __restrict__ meta, const double* __restrict__ Kc, double* __restrict__ data) {
-    const int64_t sb = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (sb >= n_blk) return;
-    const int32_t beg = segptr[sb], end = segptr[sb + 1];
-    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-    for (int32_t t = beg; t < end; ++t) {
-        const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)perm[t] * 4);
-        const double2 r0 = src[0], r1 = src[1];
-        a00 += r0.x; a01 += r0.y; a10 += r1.x; a11 += r1.y;
+csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t* __restrict__ segptr,
+                  const int32_t* __restrict__ perm, const uint32_t* __restrict__ meta,
+                  const double* __restrict__ Kc, double* __restrict__ data) {
+    // one workgroup = one tile of whole nodes, blocks [tstart[g], tstart[g+1]) (<= kBlock): its 4*nb CSR values
+    // are one contiguous range, staged in LDS and written as full consecutive lines (a lane's two 16-byte pieces
+    // belong to two different rows; direct stores fill every line in two half passes)
+    __shared__ double2 out2[2 * kBlock];
+    const int g = blockIdx.x;
+    if (g >= n_tiles) return;
+    const int64_t sb0 = tstart[g];
+    const int nb = tstart[g + 1] - (int)sb0;
+    const int64_t sb = sb0 + threadIdx.x;
+    if ((int)threadIdx.x < nb) {
+        const int32_t beg = segptr[sb], end = segptr[sb + 1];
+        const uint32_t m = meta[sb];
+        double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+        for (int32_t t = beg; t < end; ++t) {
+            const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)perm[t] * 4);
+            const double2 r0 = src[0], r1 = src[1];
+            a00 += r0.x; a01 += r0.y; a10 += r1.x; a11 += r1.y;
+        }
+        const int sl = (int)(m & 0x7fffu), deg = (int)(m >> 16);
+        const int rel = 2 * (int)threadIdx.x - sl;          // (CSR position - 4*sb0) / 2
+        out2[rel] = make_double2(a00, a01);
+        out2[rel + deg] = make_double2(a10, a11);
     }
-    const uint32_t m = meta[sb];
-    const int64_t s = m & 0x7fffu, deg = m >> 16;
-    const int64_t pos0 = 4 * sb - 2 * s;
-    *reinterpret_cast<double2*>(data + pos0) = make_double2(a00, a01);
-    *reinterpret_cast<double2*>(data + pos0 + 2 * deg) = make_double2(a10, a11);
+    __syncthreads();
+    double2* dst = reinterpret_cast<double2*>(data + 4 * sb0);
+    for (int i = threadIdx.x; i < 2 * nb; i += kBlock) dst[i] = out2[i];
 }
 
 // Internal force: one lane per node; sums the element pairs fe[(a*n_e+e)*2 + i] in incidence order.
