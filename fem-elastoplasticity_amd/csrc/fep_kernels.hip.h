@@ -615,11 +615,14 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
         }
     }
     if (DIAG) { st1 = (long long)__builtin_amdgcn_s_memtime(); }
-    // (2) operand loads: every lane loads (slots past the list repeat a valid element), no branch
+    // (2) operand loads.  Wave-uniform guard: a wave whose 64 slots all lie past the list issues nothing
+    // (with L = 150 of 256 slots that is one wave in four: the kernel's time follows its vector-memory
+    // instruction count); inside a wave every lane loads (slots past the list repeat a valid element).
     double2 g0[EPT], g1[EPT], g2[EPT], g3[EPT];        // 64-byte geometry record (4 x 16-byte loads; the SoA dphi
     double dv[EPT][6], sv[EPT][3];                      // arrays as 7 x 8-byte loads measured 5-10 us slower)
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
+        if (r * TPB + (int)(threadIdx.x & ~63u) >= L) continue;
         const int64_t e = el[r];
         const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
         g0[r] = g[0]; g1[r] = g[1]; g2[r] = g[2]; g3[r] = g[3];
