@@ -180,6 +180,7 @@ def main():
         k_ms = kms['element']
         k_name = 'element_kernel<3,1,true> (strain + return map + K_e/f_e)'
         others = {'csr_reduce_kernel': kms['csr'], 'force_reduce_kernel': kms['force']}
+        per_kernel = None
     else:
         # node route: the priced work (return map + tangent assembly) is the PAIR of kernels; the
         # figure divides SURVEY 8d's bytes by the SUM of both durations (which also includes the CSR
@@ -187,6 +188,15 @@ def main():
         k_ms = kms['element'] + kms['csr']
         k_name = 'p1_point_kernel + p1_node_kernel (strain + return map; tangent CSR values + force)'
         others = {'p1_point_kernel': kms['element'], 'p1_node_kernel': kms['csr']}
+        # each kernel against its OWN minimal HBM bytes: point = elem ids 12 + ep 32 + materials 32
+        # + coordinates/displacements 32 (16 B per node, ~2 elements per node) + s 32 + ds 72 + ind_p 1 = 213 B;
+        # assembly = ds 48 (6 of 9 rows) + s 24 + geometry 56 + descriptors/codes 32 + CSR values 8*nnz/n + force 16*n_n/n
+        b_point = 213.0 * n_int
+        b_node = (48 + 24 + 56 + 32) * n_int + 8.0 * ctx.nnz + 8.0 * ctx.n_dof
+        per_kernel = {'p1_point_kernel': {'bytes': b_point, 'GBps': b_point / (kms['element'] * 1e-3) / 1e9,
+                                          'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                      'p1_node_kernel': {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
+                                         'frac': b_node / (kms['csr'] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     alg = ALG_BYTES['P1'] * n_int
     achieved = alg / (k_ms * 1e-3) / 1e9
 
@@ -215,7 +225,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': k_name, 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_launch': alg, 'timing': f'HIP events in situ, mean of {n_prof} launches',
-                         'kernels_ms': others},
+                         'kernels_ms': others, 'per_kernel': per_kernel},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(fep)

@@ -484,3 +484,64 @@ def test_p2_one_million_points_divergence_stress(fep):
     # against rigid translations)
     assert abs(r['F'][0::2].sum()) <= 1e-9 * np.abs(r['F']).sum() and abs(r['F'][1::2].sum()) <= 1e-9 * np.abs(r['F']).sum()
     ctx.close()
+
+
+# ---- special values and wide parameter ranges of the return map --------------------------------------
+def test_return_map_special_values_vs_oracle(fep):
+    """Zero strain, points exactly on the switching surfaces, pure volumetric / pure deviatoric strains,
+    very small and very large magnitudes.  Branch decisions must be identical (strict > / <= as DP:693-699)."""
+    sh0, bu0, eta0, c0 = [v[0] for v in dp_materials(1)]
+    rows = []
+    rows.append((0.0, 0.0, 0.0))                                    # zero strain: elastic, rho = 0
+    rows.append((1e-300, -1e-300, 1e-300))                          # denormal-range products
+    rows.append((5e-4, 5e-4, 0.0))                                  # pure volumetric tension: apex with rho = 0 (C6 corner)
+    rows.append((-5e-4, -5e-4, 0.0))                                # pure volumetric compression: elastic
+    rows.append((3e-4, -3e-4, 0.0))                                 # pure deviatoric
+    rows.append((0.0, 0.0, 7e-4))                                   # pure shear
+    for sc in (1e-12, 1e-9, 1e-6, 1e-3, 1e-1, 1e2):                 # magnitudes over 14 decades
+        rows.append((1.3 * sc, -0.4 * sc, 0.9 * sc))
+        rows.append((-1.1 * sc, -0.7 * sc, 0.2 * sc))
+    E = np.array(rows).T.copy()
+    n = E.shape[1]
+    sh, bu, eta, c = sh0 * np.ones(n), bu0 * np.ones(n), eta0 * np.ones(n), c0 * np.ones(n)
+    # a point tuned to sit on crit1 == 0 as closely as fp64 allows, and one on crit2 == 0
+    from scipy.optimize import brentq
+
+    def crit(g, which):
+        r = orc.return_map(np.array([[0.0], [0.0], [g]]), None, sh[:1], bu[:1], eta[:1], c[:1])
+        return (1.0 if r['ind_p'][0] else -1.0) if which == 1 else 0.0
+    g1 = brentq(lambda g: crit(g, 1), 1e-6, 1e-2, xtol=1e-22, rtol=8.9e-16)
+    E = np.concatenate([E, np.array([[0.0, 0.0], [0.0, 0.0], [g1, np.nextafter(g1, 1.0)]])], axis=1)
+    n = E.shape[1]
+    sh, bu, eta, c = sh0 * np.ones(n), bu0 * np.ones(n), eta0 * np.ones(n), c0 * np.ones(n)
+    ep = np.zeros((4, n))
+    with np.errstate(all='ignore'):
+        o = orc.return_map(E, ep.copy(), sh, bu, eta, c, True)
+    a = fep.construct_constitutive_problem(E, ep.copy(), sh, bu, eta, c, True)
+    assert np.array_equal(a['ind_p'], o['ind_p'])
+    fin = np.isfinite(o['s']).all(axis=0) & np.isfinite(o['ds']).all(axis=0)
+    assert fin.sum() >= n - 1                                        # only the rho = 0 apex corner may be non-finite
+    assert relerr(a['s'][:, fin], o['s'][:, fin]) <= TOL_PT and relerr(a['ds'][:, fin], o['ds'][:, fin]) <= TOL_PT
+    assert np.array_equal(np.isnan(a['ds']), np.isnan(o['ds'])) and np.array_equal(np.isnan(a['s']), np.isnan(o['s']))
+    assert relerr(a['ep'][:, fin], o['ep'][:, fin]) <= TOL_PT
+
+
+def test_return_map_random_materials_wide_ranges(fep):
+    rng = np.random.default_rng(2025)
+    n = 50_000
+    sh = 10 ** rng.uniform(2, 9, n)
+    bu = sh * 10 ** rng.uniform(-1, 2, n)
+    eta = rng.uniform(0.01, 0.9, n)
+    c = 10 ** rng.uniform(-2, 5, n)
+    scale = c / sh                                                   # strains around the yield strain of each point
+    E = rng.normal(0, 1, size=(3, n)) * scale * 10 ** rng.uniform(-2, 1.5, n)
+    ep = rng.normal(0, 0.1, size=(4, n)) * scale
+    a = fep.construct_constitutive_problem(E, ep.copy(), sh, bu, eta, c, True)
+    o = orc.return_map(E, ep.copy(), sh, bu, eta, c, True)
+    assert 0.1 * n < o['n_smooth'] and 0.02 * n < o['n_apex'] < 20000
+    assert np.array_equal(a['ind_p'], o['ind_p'])
+    # per-point relative error (the arrays span 10 decades, so a global max norm would hide small points)
+    for key in ('s', 'ds', 'ep'):
+        ref = o[key]
+        den = np.abs(ref).max(axis=0) + 1e-300
+        assert (np.abs(a[key] - ref).max(axis=0) / den).max() <= 5e-12, key
