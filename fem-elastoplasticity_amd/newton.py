@@ -43,10 +43,12 @@ def _energy(K, v):
 
 
 def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, max_steps=None, zeta_max=1.0,
-                        device=None, log=None):
+                        device=None, log=None, context_factory=None):
     """Strip-footing benchmark of Plasticity2D_DP (DP:901-1131).  `level` as in the reference
     (N = size_xy * 2**level cells per side) or `n_cells` directly.  Returns a dict with the load history
-    ('zeta', 'pressure'), the accepted displacements 'U' (list of (2,n_n)), final 'Ep', counters."""
+    ('zeta', 'pressure'), the accepted displacements 'U' (list of (2,n_n)), final 'Ep', counters.
+    `context_factory(elements, coordinates, dhatp1, dhatp2, wf)` may supply another object with MeshContext's
+    `set_materials / step / geometry / close` (the tests drive the same loop with the CPU oracle that way)."""
     t = _coerce(element_type)
     young, poisson, c0, phi = 1e7, 0.48, 450, np.pi / 9                                   # DP:910-933
     shear0 = young / (2 * (1 + poisson))
@@ -58,7 +60,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     q_nd = mesh['dirichlet_nodes'][1, :] > 0
     n_n = coord.shape[1]
     d1, d2, wf = element_tables(t)
-    ctx = MeshContext(elem, coord, d1, d2, wf, device=device)
+    ctx = (context_factory or (lambda *a: MeshContext(*a, device=device)))(elem, coord, d1, d2, wf)
     n_int = ctx.n_int
     ctx.set_materials(shear0, bulk0, eta0, c_0)
     K_elast = ctx.step(np.zeros(2 * n_n), want=('K',))['K']                               # DP:977

@@ -97,3 +97,46 @@ def test_config2_65k_p1_single_load_step(fep):
     # converged: the residual vanishes on the free DOFs
     qf = mesh['Q'].flatten(order='F')
     assert np.abs(r['F'][qf]).max() <= 1e-8 * np.abs(r['F']).max()
+
+
+class _OracleContext:
+    """MeshContext look-alike backed by the CPU oracle (test infrastructure): same driver loop, other hot path."""
+
+    def __init__(self, elem, coord, d1, d2, wf):
+        from oracle import fep_oracle as orc
+        self.orc, self.elem, self.coord, self.tab = orc, elem, coord, (d1, d2, wf)
+        self.n_int = elem.shape[1] * wf.size
+
+    def set_materials(self, sh, bu, eta, c):
+        one = np.ones(self.n_int)
+        self.m = (sh * one, bu * one, eta * one, c * one)
+        K, B, w, iD, jD, D = self.orc.elastic_setup(self.elem, self.coord, self.m[0], self.m[1], *self.tab)
+        self.c = dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=self.m[0], bulk=self.m[1],
+                      eta=self.m[2], c=self.m[3])
+
+    def geometry(self):
+        return None, None, self.c['weight'], None
+
+    def step(self, U, ep_prev=None, apply_plastic_strain=False, want=()):
+        U2 = np.asarray(U).reshape((2, -1), order='F') if np.ndim(U) == 1 else U
+        E, cp, K_t, F = self.orc.hot_path(U2, ep_prev, self.c, apply_plastic_strain=apply_plastic_strain)
+        return {'K': K_t.tocsr(), 'F': F, 's': cp['s'], 'ds': cp['ds'], 'ind_p': cp['ind_p'],
+                'n_smooth': cp['n_smooth'], 'n_apex': cp['n_apex']}
+
+    def close(self):
+        pass
+
+
+def test_config4_in_miniature_ten_load_steps_gpu_vs_oracle_driver(fep):
+    """BASELINE configs[3] scaled down (N=48: 4 608 P1 elements, 10 accepted load steps): the SAME driver loop is
+    run with the GPU hot path and with the CPU oracle as hot path; every accepted displacement, the load history,
+    the plastic-point counts and the final plastic strain must agree."""
+    a = fep.solve_strip_footing('P1', n_cells=48, max_steps=10)
+    b = fep.solve_strip_footing('P1', n_cells=48, max_steps=10, context_factory=_OracleContext)
+    assert len(a['zeta']) == len(b['zeta']) == 10 and np.allclose(a['zeta'], b['zeta'], rtol=0, atol=1e-15)
+    assert a['n_calls'] == b['n_calls'] and a['newton_its'] == b['newton_its']
+    assert a['counts'] == b['counts'] and a['counts'][-1][0] > 500          # well into the plastic regime
+    for k in range(10):
+        assert relerr(a['U'][k], b['U'][k]) <= 1e-10, k
+    assert np.abs(np.array(a['pressure']) - np.array(b['pressure'])).max() <= 1e-9 * max(b['pressure'])
+    assert relerr(a['Ep'], b['Ep']) <= 1e-9
