@@ -49,8 +49,9 @@ struct fep_ctx {
     int32_t *perm2 = nullptr, *ncol = nullptr;
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr, *wg_rng = nullptr;   // wg_rng: <= 8 (start, cum) runs per tile
     bool p1_rng = false, p1_pk = false;
-    uint32_t* pk = nullptr;                             // packed block descriptors (beg_local | len | deg | slot | diag)
-    int32_t *tile_fnode0 = nullptr, *tstart = nullptr;  // tstart: first block of every tile (tiles hold whole nodes)
+    uint2* pk = nullptr;                                // packed block descriptors, lanes sorted by segment length
+    int2* tile_fnode0 = nullptr;                        // (first node, number of nodes) per tile
+    int32_t* tstart = nullptr;  // tstart: first block of every tile (tiles hold whole nodes)
     int n_wg_p1 = 0;   // LDS-staged variant: per-workgroup element lists
     uint16_t* perm_l = nullptr;
     int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
@@ -531,26 +532,40 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                 }
                 c->p1_rng = fits;
                 if (fits) CK(upload(&c->wg_rng, rng.data(), (int64_t)rng.size()));
-                // packed block descriptors, if every field fits its bit width
-                std::vector<uint32_t> pkv((size_t)c->n_blk);
-                std::vector<int32_t> fn0((size_t)n_wg, 0);
-                bool pk_ok = CP <= 2047 && !(pth && std::strcmp(pth, "node_unpacked") == 0);
+                // packed block descriptors, if every field fits its bit width; lanes sorted by segment length
+                std::vector<uint2> pkv((size_t)c->n_blk);
+                std::vector<int2> fn0((size_t)n_wg, make_int2(0, 0));
+                bool pk_ok = CP <= 2047 && TILE <= 256 && !(pth && std::strcmp(pth, "node_unpacked") == 0);
+                std::vector<int> order(TILE);
                 for (int64_t g = 0; g < n_wg && pk_ok; ++g) {
                     const int64_t b0 = tstart[g], b1 = tstart[g + 1];
                     const int32_t t0 = S.segptr[b0];
-                    bool seen = false;
-                    int32_t prev = -1;
-                    for (int64_t b = b0; b < b1; ++b) {
+                    const int nb = (int)(b1 - b0);
+                    for (int k = 0; k < nb; ++k) order[k] = k;
+                    std::stable_sort(order.begin(), order.begin() + nb, [&](int x, int y) {
+                        return S.segptr[b0 + x + 1] - S.segptr[b0 + x] > S.segptr[b0 + y + 1] - S.segptr[b0 + y];
+                    });
+                    // node index inside the tile of every block (tiles hold whole, consecutive nodes)
+                    int knode = -1;
+                    std::vector<int> node_of(nb);
+                    int32_t first_node = -1;
+                    for (int k = 0; k < nb; ++k) {
+                        if ((S.meta[b0 + k] & 0x7fffu) == 0) ++knode;
+                        node_of[k] = knode;
+                        if ((S.meta[b0 + k] >> 15) & 1u) { if (first_node < 0 || S.ncol[b0 + k] < first_node) first_node = S.ncol[b0 + k]; }
+                    }
+                    fn0[g] = make_int2(first_node < 0 ? 0 : first_node, knode + 1);
+                    if (knode + 1 > 255) { pk_ok = false; break; }
+                    for (int lane = 0; lane < nb; ++lane) {
+                        const int k = order[lane];
+                        const int64_t b = b0 + k;
                         const uint32_t mt = S.meta[b];
                         const uint32_t len = (uint32_t)(S.segptr[b + 1] - S.segptr[b]), deg = mt >> 16, slot = mt & 0x7fffu;
                         const uint32_t diag = (mt >> 15) & 1u;
                         if (len > 15 || deg > 255 || slot > 255) { pk_ok = false; break; }
-                        pkv[b] = (uint32_t)(S.segptr[b] - t0) | (len << 11) | (deg << 15) | (slot << 23) | (diag << 31);
-                        if (diag) {      // diagonal lanes of a tile must belong to consecutive nodes
-                            if (!seen) { fn0[g] = S.ncol[b]; seen = true; }
-                            else if (S.ncol[b] != prev + 1) { pk_ok = false; break; }
-                            prev = S.ncol[b];
-                        }
+                        if (diag && S.ncol[b] != fn0[g].x + node_of[k]) { pk_ok = false; break; }   // consecutive node ids
+                        pkv[b0 + lane] = make_uint2((uint32_t)(S.segptr[b] - t0) | (len << 11) | (deg << 15) | (slot << 23) | (diag << 31),
+                                                    (uint32_t)k | ((uint32_t)node_of[k] << 8));
                     }
                 }
                 c->p1_pk = pk_ok;

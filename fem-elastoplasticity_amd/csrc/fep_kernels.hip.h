@@ -552,16 +552,17 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 // (start_r, cumulative count_r), fetched with scalar loads; the operand loads then depend on no vector
 // load at all, which takes one memory round trip out of every workgroup's critical path.  Chosen by the
 // host whenever every tile's list compresses into 8 runs (any mesh numbered with locality).
-// PK = true: the lane's block descriptor is ONE packed word (pk: beg_local:11 | len:4 | deg:8 | slot:8 | diag:1)
-// instead of segptr x2 + meta + ncol (16 -> 4 bytes per block = 42 MB per launch at 1 M elements); the node that a
-// diagonal lane sums the force for is tile_fnode0[tile] + (number of diagonal lanes before it in the tile).
+// PK = true: the lane's block descriptor is ONE 8-byte load (pk.x: beg_local:11 | len:4 | deg:8 | slot:8 | diag:1,
+// pk.y: block index in the tile | node index in the tile << 8) instead of segptr x2 + meta + ncol, and the lanes of
+// a tile are SORTED by descending segment length: the diagonal blocks (one contribution per incident element, 6 on
+// a regular mesh, against 2 for an edge block) fill the first wave instead of setting the trip count of all four.
 template <bool DIAG, int TPB, bool RNG, int EPT, bool PK>
 __global__ void __launch_bounds__(TPB)
 p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
                    const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
                    const int32_t* __restrict__ ncol,
                    const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
-                   const uint32_t* __restrict__ pk, const int32_t* __restrict__ tile_fnode0,
+                   const uint2* __restrict__ pk, const int2* __restrict__ tile_fnode0,
                    const int32_t* __restrict__ tstart,
                    const double* __restrict__ geo,
                    const double* __restrict__ DS, const double* __restrict__ S,
@@ -636,8 +637,13 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // (3) the lane's block descriptors and the tile's gather codes: independent of (1)-(2), consumed last
     int32_t beg, end, ncol_sb = -1;
     uint32_t m;
+    uint32_t pk_y = 0;
     if (PK) {
-        const uint32_t w = live ? pk[sb] : 0u;
+        // lanes of a tile are sorted by descending segment length (host): pk.y = block index inside the tile |
+        // index of the lane's node inside the tile << 8
+        const uint2 w2 = live ? pk[sb] : make_uint2(0u, 0u);
+        const uint32_t w = w2.x;
+        pk_y = w2.y;
         beg = (int32_t)(w & 2047u);
         end = beg + (int32_t)((w >> 11) & 15u);
         m = (((w >> 15) & 255u) << 16) | ((w >> 31) << 15) | ((w >> 23) & 255u);     // deg | diag | slot
@@ -679,24 +685,15 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
         if (ci < CW) codes32[ci] = cd[q];
     }
     __shared__ int32_t t0_sh;
-    __shared__ int32_t wdiag[TPB / 64];
     const bool is_diag = (m >> 15) & 1u;
-    unsigned long long dmask = 0;
-    if (PK) {
-        dmask = __ballot(is_diag);
-        if ((threadIdx.x & 63) == 0) wdiag[threadIdx.x >> 6] = __popcll(dmask);
-    } else if (threadIdx.x == 0) {
-        t0_sh = beg;
-    }
+    if (!PK && threadIdx.x == 0) t0_sh = beg;
     if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st3 = (long long)__builtin_amdgcn_s_memtime(); }   // this wave's staging done
     __syncthreads();
     if (DIAG) st4 = (long long)__builtin_amdgcn_s_memtime();                                       // barrier released
     int32_t t0, fnode_k = -1;
     if (PK) {
         t0 = 0;                                        // pk holds tile-local code offsets
-        int before = __popcll(dmask & ((1ull << (threadIdx.x & 63)) - 1ull));
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wdiag[w];
-        fnode_k = is_diag ? before : -1;               // k-th node of the tile
+        fnode_k = is_diag ? (int)((pk_y >> 8) & 255u) : -1;       // k-th node of the tile
     } else {
         t0 = t0_sh;
     }
@@ -731,7 +728,8 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     double2* out2 = reinterpret_cast<double2*>(rec);
     if (live && data) {
         const int64_t sl = m & 0x7fffu, deg = m >> 16;
-        const int rel = 4 * (int)threadIdx.x - 2 * (int)sl;      // = CSR position - 4*sb0, always even
+        const int blk = PK ? (int)(pk_y & 255u) : (int)threadIdx.x;   // block index inside the tile
+        const int rel = 4 * blk - 2 * (int)sl;                   // = CSR position - 4*sb0, always even
         out2[rel >> 1] = make_double2(k00, k01);
         out2[(rel >> 1) + (int)deg] = make_double2(k10, k11);
     }
@@ -744,10 +742,9 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     }
     if (F != nullptr && S != nullptr) {
         if (PK) {
-            int ndiag = 0;
-            for (int w = 0; w < TPB / 64; ++w) ndiag += wdiag[w];
-            double2* dstf = reinterpret_cast<double2*>(F + 2 * (int64_t)tile_fnode0[wg]);
-            if ((int)threadIdx.x < ndiag) dstf[threadIdx.x] = fo2[threadIdx.x];
+            const int2 tf = tile_fnode0[wg];           // (first node of the tile, number of nodes)
+            double2* dstf = reinterpret_cast<double2*>(F + 2 * (int64_t)tf.x);
+            if ((int)threadIdx.x < tf.y) dstf[threadIdx.x] = fo2[threadIdx.x];
         } else if (want_f) {
             *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol_sb) = make_double2(f0, f1);
         }
