@@ -141,6 +141,11 @@ int fep_ctx_device_ptr(const fep_ctx* ctx, int which, void** ptr_d);
  *   s, ds, ind_p   as in fep_return_map_*; any of them may be NULL when not wanted
  *   k_data     out (nnz)     f_out  out (n_dof)
  *   counts     out [2] {n_smooth, n_apex} or NULL
+ *
+ * No allocation and no synchronisation happens in fep_step_dev once every output the caller wants has been
+ * passed at least once (internal ds / s scratch is allocated on first use when k_data / f_out are requested
+ * without ds / s), so the call can be captured into a hipGraph.  Results are bitwise reproducible run to run
+ * (fixed summation order, no floating-point atomics).
  */
 int fep_step_dev(fep_ctx* ctx, void* stream, const double* u_d, const double* e0_h,
                  double* ep_prev_d, int accept,
@@ -172,8 +177,10 @@ int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d,
  * Between fep_ctx_profile_begin and fep_ctx_profile_end every fep_step_dev / fep_assemble_dev call
  * brackets each of its kernels with HIP events on the launch stream (the kernels run in their real
  * position inside the step, not replayed back to back).  _end synchronises the stream and returns
- * the average milliseconds per launch: ms_out[0] fused element kernel (strain + return map + K_e,
- * f_e), ms_out[1] CSR numeric phase, ms_out[2] force gather; *n_steps = steps averaged. */
+ * the average milliseconds per launch.  P1 (node route): ms_out[0] p1_point_kernel (strain + return map),
+ * ms_out[1] p1_node_lds_kernel (tangent CSR values + force), ms_out[2] 0.  Other element types / COO route:
+ * ms_out[0] element_kernel (strain + return map + K_e, f_e), ms_out[1] csr_reduce_kernel, ms_out[2]
+ * force_reduce_kernel.  *n_steps = steps averaged. */
 int fep_ctx_profile_begin(fep_ctx* ctx);
 int fep_ctx_profile_end(fep_ctx* ctx, void* stream, double ms_out[3], int* n_steps);
 
