@@ -53,3 +53,45 @@ def test_shards_reproduce_global_step(fep, t, nx, ny, world):
         F[sc.iface_local_dofs] = buf[sc.iface_slot_dofs]
         assert relerr(F, ref['F'][dofs]) <= 1e-12
         sc.close()
+
+
+def test_step_dev_is_graph_capturable_and_device_resident(fep):
+    """fep_step_dev on caller-owned device buffers (torch tensors): captured into a HIP graph, replayed, and equal
+    bit for bit to the host-array entry point."""
+    import torch
+    mesh = fep.square_mesh(40, 'P1', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n = elem.shape[1]
+    sh, bu, eta, c = dp_materials(n)
+    x, y = coord
+    U = np.array([2.5e-4 * y * (x / 10) + 1.2e-4 * x * (y > 5), -1.5e-4 * y * (x < 5) + 2.0e-4 * y * (x >= 5)])
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh, bu, eta, c)
+    ref = ctx.step(U, np.zeros((4, n)), want=('s', 'ds', 'ind_p', 'K', 'F'))
+    dev = torch.device('cuda', 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    Ud = torch.from_numpy(np.ascontiguousarray(U.reshape(-1, order='F'))).to(dev)
+    Ep = torch.zeros((4, n), **f64); S = torch.zeros((4, n), **f64); DS = torch.zeros((9, n), **f64)
+    ind = torch.zeros(n, dtype=torch.uint8, device=dev); Kd = torch.zeros(ctx.nnz, **f64); F = torch.zeros(ctx.n_dof, **f64)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def launch():
+        ctx.step_dev(torch.cuda.current_stream().cuda_stream, Ud.data_ptr(), ep=Ep.data_ptr(), s=S.data_ptr(),
+                     ds=DS.data_ptr(), ind_p=ind.data_ptr(), k_data=Kd.data_ptr(), f_out=F.data_ptr(), counts=cnt.data_ptr())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                                  # warm-up outside capture (lazy allocations)
+        launch()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch()
+    for t in (S, DS, Kd, F):
+        t.zero_()
+    cnt.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(S.cpu().numpy(), ref['s']) and np.array_equal(DS.cpu().numpy(), ref['ds'])
+    assert np.array_equal(Kd.cpu().numpy(), ref['K'].data) and np.array_equal(F.cpu().numpy(), ref['F'])
+    assert np.array_equal(ind.cpu().numpy().astype(bool), ref['ind_p'])
+    assert tuple(cnt.cpu().tolist()) == (ref['n_smooth'], ref['n_apex'])
+    ctx.close()
