@@ -49,6 +49,14 @@ PROTOTYPES = {
     'fep_assemble_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_gather_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_scatter_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_transform_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_transform_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_solver_create': (C.c_int, [c_void_pp, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_solver_destroy': (C.c_int, [C.c_void_p]),
+    'fep_solver_sizes': (C.c_int, [C.c_void_p, c_i64_p]),
+    'fep_solver_spmv_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'fep_solver_pcg_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                     C.c_int, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)]),
     'fep_ctx_profile_begin': (C.c_int, [C.c_void_p]),
     'fep_ctx_profile_end': (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
 }
@@ -78,6 +86,10 @@ def lib():
             raise ImportError(f'{path} is missing: the HIP extension has not been built '
                               f'(run `python -c "import __graft_entry__ as g; g.build()"`). '
                               f'There is no CPU fallback.')
+        # torch ships its own copy of the HIP runtime (same soname): whichever is loaded first serves the whole
+        # process, and torch finds no GPU when it comes second.  The device-resident entry points take torch
+        # tensors' memory, so load torch's runtime first.
+        import torch  # noqa: F401
         l = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported

@@ -1,6 +1,6 @@
 // C-ABI implementation of include/fep.h (libfep_hip.so).  Host side: context, symbolic
 // phase (node graph -> CSR pattern + gather lists), launches.  Device side: fep_kernels.hip.h.
-#include "../../include/fep.h"
+#include "fep_common.h"
 #include "fep_kernels.hip.h"
 
 #include <algorithm>
@@ -12,22 +12,8 @@
 
 using namespace fep;
 
-static thread_local int g_last_hip = 0;
-
-#define HIP_TRY(expr)                                   \
-    do {                                                \
-        hipError_t _e = (expr);                         \
-        if (_e != hipSuccess) {                         \
-            g_last_hip = (int)_e;                       \
-            (void)hipGetLastError();                    \
-            return _e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; \
-        }                                               \
-    } while (0)
-#define FEP_TRY(expr)                  \
-    do {                               \
-        int _r = (expr);               \
-        if (_r != FEP_OK) return _r;   \
-    } while (0)
+thread_local int fep_g_last_hip = 0;
+#define g_last_hip fep_g_last_hip
 
 struct fep_ctx {
     int device = 0;
@@ -71,7 +57,7 @@ struct fep_ctx {
     std::vector<hipEvent_t> events;
 };
 
-static int set_device(int dev) {
+__attribute__((visibility("hidden"))) int fep_set_device(int dev) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { g_last_hip = (int)e; (void)hipGetLastError(); return FEP_ENODEV; }
@@ -155,30 +141,30 @@ extern "C" int fep_element_shape(int elem_type, int* n_p, int* n_q) {
 
 extern "C" int fep_malloc(int device_id, void** ptr_d, int64_t bytes) {
     if (!ptr_d || bytes < 0) return FEP_EINVAL;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     HIP_TRY(hipMalloc(ptr_d, (size_t)(bytes > 0 ? bytes : 1)));
     return FEP_OK;
 }
 extern "C" int fep_free(int device_id, void* ptr_d) {
     if (!ptr_d) return FEP_OK;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     HIP_TRY(hipFree(ptr_d));
     return FEP_OK;
 }
 extern "C" int fep_memcpy_h2d(int device_id, void* dst_d, const void* src_h, int64_t bytes) {
     if (bytes < 0 || (bytes > 0 && (!dst_d || !src_h))) return FEP_EINVAL;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     if (bytes) HIP_TRY(hipMemcpy(dst_d, src_h, (size_t)bytes, hipMemcpyHostToDevice));
     return FEP_OK;
 }
 extern "C" int fep_memcpy_d2h(int device_id, void* dst_h, const void* src_d, int64_t bytes) {
     if (bytes < 0 || (bytes > 0 && (!dst_h || !src_d))) return FEP_EINVAL;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     if (bytes) HIP_TRY(hipMemcpy(dst_h, src_d, (size_t)bytes, hipMemcpyDeviceToHost));
     return FEP_OK;
 }
 extern "C" int fep_sync(int device_id, void* stream) {
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return FEP_OK;
 }
@@ -199,7 +185,7 @@ extern "C" int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
                                   int accept, double* s_d, double* ds_d, uint8_t* ind_p_d, int64_t* counts_d) {
     if (n_int < 0) return FEP_EINVAL;
     if (n_int > 0 && (!e_d || !shear_d || !bulk_d || !eta_d || !c_d)) return FEP_EINVAL;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     hipStream_t st = (hipStream_t)stream;
     if (counts_d) HIP_TRY(hipMemsetAsync(counts_d, 0, 2 * sizeof(int64_t), st));
     if (n_int == 0) return FEP_OK;
@@ -219,7 +205,7 @@ extern "C" int fep_return_map_host(int device_id, int64_t n_int,
     if (n_int > 0 && (!e_h || !shear_h || !bulk_h || !eta_h || !c_h)) return FEP_EINVAL;
     if (counts_h) { counts_h[0] = 0; counts_h[1] = 0; }
     if (n_int == 0) return FEP_OK;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     // the strain is copied as the dense block that contains the strided view
     const int64_t span = (n_int - 1) * e_pt_stride + 2 * e_comp_stride + 1;
     if (e_pt_stride <= 0 || e_comp_stride <= 0 || span < 3 * n_int) return FEP_EINVAL;
@@ -364,7 +350,7 @@ static int launch_geometry(fep_ctx* c) {
 
 extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (!c) return FEP_OK;
-    if (set_device(c->device) == FEP_OK) {
+    if (fep_set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
                         c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tile_fnode0, c->tstart};
@@ -387,7 +373,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     if (n_e * (int64_t)n_q >= INT32_MAX / 16) return FEP_ERANGE;
     Symbolic S;
     FEP_TRY(build_symbolic(n_p, n_e, n_n, elements_h, S));
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     fep_ctx* c = new (std::nothrow) fep_ctx();
     if (!c) return FEP_ENOMEM;
     c->device = device_id; c->elem_type = elem_type; c->n_p = n_p; c->n_q = n_q;
@@ -649,12 +635,13 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             c->n_count_blocks = (int)grid_for(c->n_int, kBlock);
         }
     }
+    // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
+    CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
+    CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
     if (!c->p1_node && !c->gn) {
         CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
         CK(upload(&c->tstart, tstart_all.data(), (int64_t)tstart_all.size()));
         c->n_wg_p1 = (int)tstart_all.size() - 1;
-        CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
-        CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
         CK(dmalloc(&c->Kc, 4 * c->n_contrib));
         CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
         int eb = 1;
@@ -695,7 +682,7 @@ extern "C" int fep_ctx_sizes(const fep_ctx* c, int64_t sizes[8]) {
 
 extern "C" int fep_ctx_geometry_host(fep_ctx* c, double* dphi1_h, double* dphi2_h, double* weight_h, double* det_h) {
     if (!c) return FEP_EINVAL;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     const size_t nb = (size_t)c->n_int * sizeof(double);
     if (dphi1_h) HIP_TRY(hipMemcpy(dphi1_h, c->dphi1, nb * c->n_p, hipMemcpyDeviceToHost));
     if (dphi2_h) HIP_TRY(hipMemcpy(dphi2_h, c->dphi2, nb * c->n_p, hipMemcpyDeviceToHost));
@@ -714,7 +701,7 @@ extern "C" int fep_ctx_pattern_host(const fep_ctx* c, int32_t* indptr_h, int32_t
 extern "C" int fep_ctx_set_materials_host(fep_ctx* c, const double* shear_h, const double* bulk_h,
                                           const double* eta_h, const double* c_h) {
     if (!c || !shear_h || !bulk_h || !eta_h || !c_h) return FEP_EINVAL;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     const size_t nb = (size_t)c->n_int * sizeof(double);
     HIP_TRY(hipMemcpy(c->shear, shear_h, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->bulk, bulk_h, nb, hipMemcpyHostToDevice));
@@ -887,7 +874,7 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
                             uint8_t* ind_p_d, double* k_data_d, double* f_out_d, int64_t* counts_d) {
     if (!c || !u_d) return FEP_EINVAL;
     if (!c->have_materials) return FEP_ESTATE;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* cnt = (unsigned long long*)counts_d;
     uint2* blk = cnt ? c->blk_counts : nullptr;
@@ -945,7 +932,7 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
                                 double* k_data_d, double* f_out_d) {
     if (!c) return FEP_EINVAL;
     if ((k_data_d && !ds_d) || (f_out_d && !s_d)) return FEP_EINVAL;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (c->p1_node) {
         FEP_TRY(prof_mark(c, st));
@@ -970,7 +957,7 @@ extern "C" int fep_step_host(fep_ctx* c, const double* u_h, const double* e0_h, 
                              double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
                              double* k_data_h, double* f_out_h, int64_t* counts_h) {
     if (!c || !u_h) return FEP_EINVAL;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     const int64_t nb = c->n_int * (int64_t)sizeof(double);
     DevBuf u, ep, eo, s, ds, ip, kd, f, cnt;
     FEP_TRY(u.from(u_h, c->n_dof * (int64_t)sizeof(double)));
@@ -999,7 +986,7 @@ extern "C" int fep_step_host(fep_ctx* c, const double* u_h, const double* e0_h, 
 extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s_h, double* k_data_h, double* f_out_h) {
     if (!c) return FEP_EINVAL;
     if ((k_data_h && !ds_h) || (f_out_h && !s_h)) return FEP_EINVAL;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     const int64_t nb = c->n_int * (int64_t)sizeof(double);
     DevBuf ds, s, kd, f;
     if (ds_h) FEP_TRY(ds.from(ds_h, 9 * nb));
@@ -1015,7 +1002,7 @@ extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s
 
 extern "C" int fep_gather_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* idx_d, double* dst_d) {
     if (n < 0 || (n > 0 && (!src_d || !idx_d || !dst_d))) return FEP_EINVAL;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     if (n == 0) return FEP_OK;
     hipLaunchKernelGGL(gather_or_zero_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, src_d, idx_d, dst_d);
     HIP_TRY(hipGetLastError());
@@ -1025,12 +1012,32 @@ extern "C" int fep_gather_f64(int device_id, void* stream, int64_t n, const doub
 extern "C" int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* src_idx_d,
                                const int32_t* dst_idx_d, double* dst_d) {
     if (n < 0 || (n > 0 && (!src_d || !src_idx_d || !dst_idx_d || !dst_d))) return FEP_EINVAL;
-    FEP_TRY(set_device(device_id));
+    FEP_TRY(fep_set_device(device_id));
     if (n == 0) return FEP_OK;
     hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, src_d, src_idx_d,
                        dst_idx_d, dst_d);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
+}
+
+extern "C" int fep_transform_dev(fep_ctx* c, void* stream, const double* q_int_d, double* q_node_d) {
+    if (!c || !q_int_d || !q_node_d) return FEP_EINVAL;
+    FEP_TRY(fep_set_device(c->device));
+    hipLaunchKernelGGL(nodal_average_kernel, dim3(grid_for(c->n_n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       c->n_n, c->n_e, c->n_q, c->iptr, c->ilist, c->weight, q_int_d, q_node_d);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+extern "C" int fep_transform_host(fep_ctx* c, const double* q_int_h, double* q_node_h) {
+    if (!c || !q_int_h || !q_node_h) return FEP_EINVAL;
+    FEP_TRY(fep_set_device(c->device));
+    DevBuf q, o;
+    FEP_TRY(q.from(q_int_h, c->n_int * (int64_t)sizeof(double)));
+    FEP_TRY(o.alloc(c->n_n * (int64_t)sizeof(double)));
+    FEP_TRY(fep_transform_dev(c, nullptr, q.as<double>(), o.as<double>()));
+    HIP_TRY(hipDeviceSynchronize());
+    return o.to(q_node_h, c->n_n * (int64_t)sizeof(double));
 }
 
 extern "C" int fep_ctx_profile_begin(fep_ctx* c) {
@@ -1044,7 +1051,7 @@ extern "C" int fep_ctx_profile_begin(fep_ctx* c) {
 extern "C" int fep_ctx_profile_end(fep_ctx* c, void* stream, double ms_out[3], int* n_steps) {
     if (!c || !ms_out) return FEP_EINVAL;
     c->profiling = false;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     double acc[3] = {0.0, 0.0, 0.0};
     const int n = (int)(c->events.size() / 4);
@@ -1068,7 +1075,7 @@ extern "C" int fep_ctx_profile_end(fep_ctx* c, void* stream, double ms_out[3], i
 extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const double* s_d, double* k_data_d,
                                         double* f_out_d, long long* stamps_h, int64_t cap, int* n_wg_out) {
     if (!c || !c->p1_node || !c->p1_lds || !ds_d || !s_d || !k_data_d || !f_out_d || !stamps_h) return FEP_EINVAL;
-    FEP_TRY(set_device(c->device));
+    FEP_TRY(fep_set_device(c->device));
     if (c->tile != 256 || !c->p1_rng || c->lds_L > 256) return FEP_EINVAL;
     const int n_wg = c->n_wg_p1;
     if (n_wg_out) *n_wg_out = n_wg;

@@ -1,0 +1,24 @@
+// Shared by the translation units of libfep_hip.so: error plumbing of the C ABI (include/fep.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/fep.h"
+
+extern __attribute__((visibility("hidden"))) thread_local int fep_g_last_hip;   // last failing hipError_t of this host thread (fep_last_hip_error)
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) {                         \
+            fep_g_last_hip = (int)_e;                   \
+            (void)hipGetLastError();                    \
+            return _e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; \
+        }                                               \
+    } while (0)
+#define FEP_TRY(expr)                  \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != FEP_OK) return _r;   \
+    } while (0)
+
+__attribute__((visibility("hidden"))) int fep_set_device(int dev);              // hipSetDevice with range check -> FEP_ENODEV

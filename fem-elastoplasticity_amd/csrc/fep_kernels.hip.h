@@ -420,6 +420,26 @@ force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t
     *reinterpret_cast<double2*>(F + 2 * n) = make_double2(f0, f1);
 }
 
+// transform (DP:760-816): value at a node = weighted mean of the values at the integration points of its
+// elements, weights = quadrature weight * |det J|.  One thread per node over the incidence lists.
+__global__ void __launch_bounds__(kBlock)
+nodal_average_kernel(int64_t n_n, int64_t n_e, int n_q, const int32_t* __restrict__ iptr,
+                     const int32_t* __restrict__ ilist, const double* __restrict__ weight,
+                     const double* __restrict__ q_int, double* __restrict__ q_node) {
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_n) return;
+    double f1 = 0.0, f2 = 0.0;
+    for (int32_t t = iptr[n]; t < iptr[n + 1]; ++t) {
+        const int64_t e = (int64_t)ilist[t] % n_e;
+        for (int q = 0; q < n_q; ++q) {
+            const double w = weight[e * n_q + q];
+            f1 += w * q_int[e * n_q + q];
+            f2 += w;
+        }
+    }
+    q_node[n] = f1 / f2;
+}
+
 // P1 geometry recomputed from the node coordinates (48 bytes gathered through L2 instead of a 64-byte
 // record streamed from HBM).  Same operations, same order, no FMA contraction as geometry_kernel, hence
 // bit-identical dphi / weight (DP:530-546, 585).  `tab` = the P1 reference-element tables.

@@ -1,0 +1,359 @@
+// Krylov solver on the tangent system of one Newton iterate (include/fep.h, "linear solve"):
+//     K[Q][:,Q] dU[Q] = -F[Q]        (np.linalg.solve at DP:1062-1066 / TSX:1781, dense in the reference)
+// Preconditioned conjugate gradients in the single-reduction form of Chronopoulos & Gear: per iteration one
+// fused vector kernel (p, s, x, r, u = M^-1 r and the partial sums of (r,u), (r,r)), one block-row SpMV
+// (w = K u with the partial sums of (w,u)) and a one-workgroup scalar kernel (alpha, beta, stopping test), all
+// stream-ordered; the host only reads 48 bytes every `check_every` iterations.  Sums are taken in a fixed
+// order (per-workgroup partials, then one tree), so a solve is reproducible run to run.
+//
+// K keeps the layout the assembly kernels write (fep_ctx pattern): DOF = 2*node + comp, the rows 2n and 2n+1 of
+// node n hold, back to back, deg(n) pairs (k_r0, k_r1) for the sorted neighbour nodes.  Constrained DOFs are
+// masked out (rows and columns), the solution is 0 there.  M = the 2x2 node blocks of K[Q][:,Q].
+#include "fep_common.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int NODES_PER_WAVE = 4;           // 8 lanes per DOF row, 8 rows per wave and pass
+constexpr int SPMV_PASSES = 4;              // passes per wave (independent, for loads in flight)
+constexpr int NODES_PER_BLOCK = (TPB / 64) * NODES_PER_WAVE * SPMV_PASSES;
+
+struct Scal {                 // device-resident scalars of one solve
+    double alpha, beta, gamma, rr, bb;
+    int32_t it;               // iterations applied to x so far
+    int32_t state;            // 0 running, 1 converged (frozen), 2 breakdown (K not positive definite on Q / NaN)
+};
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum over the workgroup, result valid in thread 0 (fixed order)
+__device__ inline double block_sum(double v, double* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+// M^-1 of node n from the diagonal 2x2 block of K with constrained DOFs replaced by identity rows/columns
+__global__ void __launch_bounds__(TPB)
+block_jacobi_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol,
+                    const uint8_t* __restrict__ free_dof, const double* __restrict__ K, double* __restrict__ minv) {
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (n >= n_n) return;
+    const int b0 = nptr[n], deg = nptr[n + 1] - b0;
+    double a = 1.0, b = 0.0, c = 0.0, d = 1.0;
+    for (int s = 0; s < deg; ++s)
+        if (ncol[b0 + s] == (int32_t)n) {
+            const double* base = K + 4 * (int64_t)b0;
+            a = base[2 * s]; b = base[2 * s + 1]; c = base[2 * deg + 2 * s]; d = base[2 * deg + 2 * s + 1];
+        }
+    const bool f0 = free_dof[2 * n] != 0, f1 = free_dof[2 * n + 1] != 0;
+    if (!f0) { a = 1.0; b = 0.0; c = 0.0; }
+    if (!f1) { d = 1.0; b = 0.0; c = 0.0; }
+    const double sym = 0.5 * (b + c);                 // K is symmetric up to the summation order
+    double det = a * d - sym * sym;
+    if (!(det > 0.0) || !(a > 0.0)) { a = 1.0; d = 1.0; det = 1.0; b = c = 0.0; }
+    const double off = (b == 0.0 && c == 0.0) ? 0.0 : -sym / det;
+    minv[3 * n] = d / det; minv[3 * n + 1] = off; minv[3 * n + 2] = a / det;
+}
+
+// r = Q b, u = M^-1 r, x = p = s = 0; partial sums of (r,u) and (r,r)
+__global__ void __launch_bounds__(TPB)
+pcg_init_kernel(int64_t n_n, const double2* __restrict__ b, const uint8_t* __restrict__ free_dof,
+                const double* __restrict__ minv, double2* __restrict__ x, double2* __restrict__ r,
+                double2* __restrict__ u, double2* __restrict__ p, double2* __restrict__ s,
+                double* __restrict__ part_g, double* __restrict__ part_r) {
+    __shared__ double sh[TPB / 64];
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    double g = 0.0, rr = 0.0;
+    if (n < n_n) {
+        double2 rv = b[n];
+        if (!free_dof[2 * n]) rv.x = 0.0;
+        if (!free_dof[2 * n + 1]) rv.y = 0.0;
+        const double m0 = minv[3 * n], m1 = minv[3 * n + 1], m2 = minv[3 * n + 2];
+        const double2 uv = make_double2(m0 * rv.x + m1 * rv.y, m1 * rv.x + m2 * rv.y);
+        const double2 z = make_double2(0.0, 0.0);
+        x[n] = z; p[n] = z; s[n] = z; r[n] = rv; u[n] = uv;
+        g = rv.x * uv.x + rv.y * uv.y;
+        rr = rv.x * rv.x + rv.y * rv.y;
+    }
+    g = block_sum(g, sh);
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) { part_g[blockIdx.x] = g; part_r[blockIdx.x] = rr; }
+}
+
+// p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s, u = M^-1 r; partial sums of (r,u), (r,r)
+__global__ void __launch_bounds__(TPB)
+pcg_update_kernel(int64_t n_n, const Scal* __restrict__ sc, const double2* __restrict__ w,
+                  const double* __restrict__ minv, double2* __restrict__ x, double2* __restrict__ r,
+                  double2* __restrict__ u, double2* __restrict__ p, double2* __restrict__ s,
+                  double* __restrict__ part_g, double* __restrict__ part_r) {
+    __shared__ double sh[TPB / 64];
+    const double alpha = sc->alpha, beta = sc->beta;
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    double g = 0.0, rr = 0.0;
+    if (n < n_n) {
+        const double2 uv = u[n], wv = w[n];
+        double2 pv = p[n], sv = s[n], xv = x[n], rv = r[n];
+        pv.x = uv.x + beta * pv.x; pv.y = uv.y + beta * pv.y;
+        sv.x = wv.x + beta * sv.x; sv.y = wv.y + beta * sv.y;
+        xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+        rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
+        const double m0 = minv[3 * n], m1 = minv[3 * n + 1], m2 = minv[3 * n + 2];
+        const double2 un = make_double2(m0 * rv.x + m1 * rv.y, m1 * rv.x + m2 * rv.y);
+        if (alpha != 0.0 || beta != 0.0) { p[n] = pv; s[n] = sv; x[n] = xv; r[n] = rv; u[n] = un; }
+        g = rv.x * un.x + rv.y * un.y;
+        rr = rv.x * rv.x + rv.y * rv.y;
+    }
+    g = block_sum(g, sh);
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) { part_g[blockIdx.x] = g; part_r[blockIdx.x] = rr; }
+}
+
+// y = Q K x (x is 0 on constrained DOFs by construction when MASKED); optional partial sums of (y, dotv)
+template <bool MASKED>
+__global__ void __launch_bounds__(TPB)
+spmv_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol,
+            const uint8_t* __restrict__ free_dof, const double2* __restrict__ K2, const double2* __restrict__ x,
+            double* __restrict__ y, const double* __restrict__ dotv, double* __restrict__ part_d) {
+    __shared__ double sh[TPB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 7, grp = lane >> 3;            // 8 lanes per DOF row
+    const int comp = grp & 1;
+    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + (grp >> 1);
+    double dot = 0.0;
+    double acc[SPMV_PASSES];
+    int64_t nn[SPMV_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+        const int64_t n = node0 + ps * NODES_PER_WAVE;
+        nn[ps] = n;
+        acc[ps] = 0.0;
+        if (n < n_n) {
+            const int b0 = nptr[n], deg = nptr[n + 1] - b0;
+            const double2* row = K2 + 2 * (int64_t)b0 + (int64_t)comp * deg;
+            for (int t = sub; t < deg; t += 8) {
+                const double2 k = row[t];
+                const double2 xv = x[ncol[b0 + t]];
+                acc[ps] += k.x * xv.x + k.y * xv.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+        double a = acc[ps];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        const int64_t n = nn[ps];
+        if (sub == 0 && n < n_n) {
+            const int64_t dof = 2 * n + comp;
+            if (MASKED && !free_dof[dof]) a = 0.0;
+            y[dof] = a;
+            if (dotv) dot += a * dotv[dof];
+        }
+    }
+    if (part_d) {
+        dot = block_sum(dot, sh);
+        if (threadIdx.x == 0) part_d[blockIdx.x] = dot;
+    }
+}
+
+__device__ inline double sum_partials(const double* part, int n, double* sh) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    return block_sum(v, sh);
+}
+
+// one workgroup: gamma' = (r,u), delta = (w,u), rr = (r,r) from the partials; next alpha, beta; stopping test
+__global__ void __launch_bounds__(1024)
+pcg_scalar_kernel(Scal* sc, const double* part_g, const double* part_r, int n_vec, const double* part_d, int n_mv,
+                  double tol2, int first) {
+    __shared__ double sh[16];
+    const double g = sum_partials(part_g, n_vec, sh);
+    const double rr = sum_partials(part_r, n_vec, sh);
+    const double d = sum_partials(part_d, n_mv, sh);
+    if (threadIdx.x != 0) return;
+    Scal s = *sc;
+    if (first) {
+        s.bb = rr; s.rr = rr; s.gamma = g; s.it = 0; s.state = 0; s.beta = 0.0;
+        if (rr == 0.0) { s.state = 1; s.alpha = 0.0; }
+        else if (!(g > 0.0) || !(d > 0.0)) { s.state = 2; s.alpha = 0.0; }
+        else s.alpha = g / d;
+        *sc = s;
+        return;
+    }
+    if (s.state != 0) return;                               // frozen: alpha = beta = 0 leave x untouched
+    s.it += 1;
+    s.rr = rr;
+    if (rr <= tol2 * s.bb) { s.state = 1; s.alpha = 0.0; s.beta = 0.0; *sc = s; return; }
+    const double beta = g / s.gamma;
+    const double den = d - beta * g / s.alpha;
+    if (!(g > 0.0) || !(den > 0.0) || !(beta == beta)) { s.state = 2; s.alpha = 0.0; s.beta = 0.0; *sc = s; return; }
+    s.beta = beta;
+    s.alpha = g / den;
+    s.gamma = g;
+    *sc = s;
+}
+
+}  // namespace
+
+struct fep_solver {
+    int device = 0;
+    int64_t n_n = 0, n_dof = 0, n_blk = 0, n_free = 0;
+    int32_t *nptr = nullptr, *ncol = nullptr;
+    uint8_t* free_dof = nullptr;
+    double *minv = nullptr, *r = nullptr, *u = nullptr, *w = nullptr, *p = nullptr, *s = nullptr;
+    double *part_g = nullptr, *part_r = nullptr, *part_d = nullptr;
+    Scal* scal = nullptr;
+    int n_vec_blocks = 0, n_mv_blocks = 0;
+};
+
+extern "C" int fep_solver_destroy(fep_solver* s) {
+    if (!s) return FEP_OK;
+    if (fep_set_device(s->device) == FEP_OK) {
+        void* ptrs[] = {s->nptr, s->ncol, s->free_dof, s->minv, s->r, s->u, s->w, s->p, s->s,
+                        s->part_g, s->part_r, s->part_d, s->scal};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+    delete s;
+    return FEP_OK;
+}
+
+extern "C" int fep_solver_create(fep_solver** out, int device_id, int64_t n_n, const int32_t* indptr_h,
+                                 const int32_t* indices_h, const uint8_t* free_dof_h) {
+    if (!out) return FEP_EINVAL;
+    *out = nullptr;
+    if (n_n <= 0 || !indptr_h || !indices_h || !free_dof_h) return FEP_EINVAL;
+    const int64_t n_dof = 2 * n_n;
+    // node graph from the DOF pattern; the layout contract is checked, not assumed
+    std::vector<int32_t> nptr((size_t)n_n + 1, 0);
+    if (indptr_h[0] != 0) return FEP_EINVAL;
+    for (int64_t n = 0; n < n_n; ++n) {
+        const int64_t a = indptr_h[2 * n], b = indptr_h[2 * n + 1], c = indptr_h[2 * n + 2];
+        if (b - a != c - b || ((b - a) & 1) || b < a) return FEP_EINVAL;
+        if (a != 4 * (int64_t)nptr[n]) return FEP_EINVAL;
+        nptr[n + 1] = nptr[n] + (int32_t)((b - a) / 2);
+    }
+    const int64_t n_blk = nptr[n_n];
+    std::vector<int32_t> ncol((size_t)n_blk);
+    for (int64_t n = 0; n < n_n; ++n) {
+        const int32_t deg = nptr[n + 1] - nptr[n];
+        const int32_t* r0 = indices_h + indptr_h[2 * n];
+        const int32_t* r1 = indices_h + indptr_h[2 * n + 1];
+        for (int32_t t = 0; t < deg; ++t) {
+            const int32_t c0 = r0[2 * t];
+            if ((c0 & 1) || r0[2 * t + 1] != c0 + 1 || r1[2 * t] != c0 || r1[2 * t + 1] != c0 + 1) return FEP_EINVAL;
+            if (c0 < 0 || c0 / 2 >= n_n) return FEP_ERANGE;
+            ncol[(size_t)nptr[n] + t] = c0 / 2;
+        }
+    }
+    FEP_TRY(fep_set_device(device_id));
+    fep_solver* s = new (std::nothrow) fep_solver();
+    if (!s) return FEP_ENOMEM;
+    s->device = device_id; s->n_n = n_n; s->n_dof = n_dof; s->n_blk = n_blk;
+    for (int64_t i = 0; i < n_dof; ++i) s->n_free += free_dof_h[i] != 0;
+    s->n_vec_blocks = (int)((n_n + TPB - 1) / TPB);
+    s->n_mv_blocks = (int)((n_n + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK);
+    int rc = FEP_OK;
+    auto up = [&](void** dst, const void* src, size_t bytes) {
+        if (rc != FEP_OK) return;
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 8);
+        if (e == hipSuccess && src) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fep_g_last_hip = (int)e; (void)hipGetLastError(); rc = e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; }
+    };
+    up((void**)&s->nptr, nptr.data(), nptr.size() * sizeof(int32_t));
+    up((void**)&s->ncol, ncol.data(), ncol.size() * sizeof(int32_t));
+    up((void**)&s->free_dof, free_dof_h, (size_t)n_dof);
+    up((void**)&s->minv, nullptr, (size_t)n_n * 3 * sizeof(double));
+    for (double** v : {&s->r, &s->u, &s->w, &s->p, &s->s}) up((void**)v, nullptr, (size_t)n_dof * sizeof(double));
+    up((void**)&s->part_g, nullptr, (size_t)s->n_vec_blocks * sizeof(double));
+    up((void**)&s->part_r, nullptr, (size_t)s->n_vec_blocks * sizeof(double));
+    up((void**)&s->part_d, nullptr, (size_t)s->n_mv_blocks * sizeof(double));
+    up((void**)&s->scal, nullptr, sizeof(Scal));
+    if (rc != FEP_OK) { fep_solver_destroy(s); return rc; }
+    *out = s;
+    return FEP_OK;
+}
+
+extern "C" int fep_solver_sizes(const fep_solver* s, int64_t sizes[4]) {
+    if (!s || !sizes) return FEP_EINVAL;
+    sizes[0] = s->n_n; sizes[1] = s->n_dof; sizes[2] = 4 * s->n_blk; sizes[3] = s->n_free;
+    return FEP_OK;
+}
+
+extern "C" int fep_solver_spmv_dev(fep_solver* s, void* stream, const double* k_data_d, const double* x_d,
+                                   double* y_d, int masked) {
+    if (!s || !k_data_d || !x_d || !y_d || x_d == y_d) return FEP_EINVAL;
+    FEP_TRY(fep_set_device(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (masked)
+        hipLaunchKernelGGL(spmv_kernel<true>, dim3(s->n_mv_blocks), dim3(TPB), 0, st, s->n_n, s->nptr, s->ncol, s->free_dof,
+                           (const double2*)k_data_d, (const double2*)x_d, y_d, (const double*)nullptr, (double*)nullptr);
+    else
+        hipLaunchKernelGGL(spmv_kernel<false>, dim3(s->n_mv_blocks), dim3(TPB), 0, st, s->n_n, s->nptr, s->ncol, s->free_dof,
+                           (const double2*)k_data_d, (const double2*)x_d, y_d, (const double*)nullptr, (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+extern "C" int fep_solver_pcg_dev(fep_solver* s, void* stream, const double* k_data_d, const double* b_d, double* x_d,
+                                  double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
+                                  int* state_out) {
+    if (!s || !k_data_d || !b_d || !x_d || !(rtol >= 0.0) || max_iter < 0) return FEP_EINVAL;
+    if (check_every <= 0) check_every = 50;
+    FEP_TRY(fep_set_device(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gv(s->n_vec_blocks), gm(s->n_mv_blocks), tb(TPB);
+    const double tol2 = rtol * rtol;
+    double2 *x = (double2*)x_d, *r = (double2*)s->r, *u = (double2*)s->u, *p = (double2*)s->p, *sv = (double2*)s->s;
+    auto spmv_dot = [&]() {
+        hipLaunchKernelGGL(spmv_kernel<true>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof,
+                           (const double2*)k_data_d, (const double2*)s->u, s->w, (const double*)s->u, s->part_d);
+    };
+    hipLaunchKernelGGL(block_jacobi_kernel, gv, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, k_data_d, s->minv);
+    hipLaunchKernelGGL(pcg_init_kernel, gv, tb, 0, st, s->n_n, (const double2*)b_d, s->free_dof, s->minv, x, r, u, p, sv,
+                       s->part_g, s->part_r);
+    spmv_dot();
+    hipLaunchKernelGGL(pcg_scalar_kernel, dim3(1), dim3(1024), 0, st, s->scal, s->part_g, s->part_r, s->n_vec_blocks,
+                       s->part_d, s->n_mv_blocks, tol2, 1);
+    HIP_TRY(hipGetLastError());
+    Scal h;
+    std::memset(&h, 0, sizeof h);
+    int launched = 0;
+    for (;;) {
+        HIP_TRY(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h.state != 0 || launched >= max_iter) break;
+        const int n = std::min(check_every, max_iter - launched);
+        for (int i = 0; i < n; ++i) {
+            hipLaunchKernelGGL(pcg_update_kernel, gv, tb, 0, st, s->n_n, s->scal, (const double2*)s->w, s->minv, x, r, u, p,
+                               sv, s->part_g, s->part_r);
+            spmv_dot();
+            hipLaunchKernelGGL(pcg_scalar_kernel, dim3(1), dim3(1024), 0, st, s->scal, s->part_g, s->part_r,
+                               s->n_vec_blocks, s->part_d, s->n_mv_blocks, tol2, 0);
+        }
+        HIP_TRY(hipGetLastError());
+        launched += n;
+    }
+    if (iters_out) *iters_out = h.it;
+    if (relres_out) *relres_out = h.bb > 0.0 ? std::sqrt(h.rr / h.bb) : 0.0;
+    if (state_out) *state_out = h.state;
+    return FEP_OK;
+}

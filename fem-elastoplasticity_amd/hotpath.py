@@ -264,6 +264,18 @@ class MeshContext:
         _lib.check(_lib.lib().fep_assemble_dev(self._h, stream, ds or None, s or None, k_data or None, f_out or None),
                    'fep_assemble_dev')
 
+    def transform(self, q_int):
+        """Nodal values of an integration-point field (DP:760-816) -> (n_n,) ndarray."""
+        q = _f64(q_int).ravel()
+        if q.size != self.n_int:
+            raise ValueError(f'q_int must hold {self.n_int} values')
+        out = np.empty(self.n_n)
+        _lib.check(_lib.lib().fep_transform_host(self._h, _lib.ptr(q), _lib.ptr(out)), 'fep_transform_host')
+        return out
+
+    def transform_dev(self, stream, q_int, q_node):
+        _lib.check(_lib.lib().fep_transform_dev(self._h, stream, q_int, q_node), 'fep_transform_dev')
+
     def profile_begin(self):
         """Start bracketing every kernel of the following step_dev/assemble_dev calls with HIP events."""
         _lib.check(_lib.lib().fep_ctx_profile_begin(self._h), 'fep_ctx_profile_begin')

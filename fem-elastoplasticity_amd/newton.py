@@ -1,16 +1,19 @@
 """
 Callers of the hot path: the reference's load-stepping / semismooth-Newton drivers
-re-stated around the GPU step, with a SciPy sparse solve in place of the reference's dense
-`np.linalg.solve` on a (2 n_n)^2 boolean-masked matrix.
+re-stated around the GPU step.
 
   solve_strip_footing   Plasticity2D_DP/pythonFEM.py:986-1131  (adaptive load steps, footing pressure)
   solve_tsx_tunnel      tsx-tunnel/pythonFEM.py:1729-1832      (17 uniform steps of the initial-stress factor;
                         the accepting call leaves `apply_plastic_strain` False)
 
-Per Newton iterate ONE call `MeshContext.step` replaces DP:1043-1058 (strain, return map, tangent, residual).
+Per Newton iterate ONE call of the fused step replaces DP:1043-1058 (strain, return map, tangent, residual).
 Step control, stopping norms and the extrapolation of the next iterate follow the reference line by line.
-`transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is host
-post-processing and is re-stated with `np.bincount`.
+The linear solve (the reference's dense `np.linalg.solve` on a (2 n_n)^2 boolean-masked matrix) is
+  linear_solver='direct'  SciPy SuperLU on the host CSR matrix (K travels to the host every iterate), or
+  linear_solver='pcg'     conjugate gradients on the GPU (solver.py); the iterate, K, F, the plastic strain and
+                          the stopping norms then never leave the device.
+`transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is re-stated
+with `np.bincount` on the host and as `fep_transform_dev` on the device.
 """
 import numpy as np
 import scipy.sparse.linalg as sspl
@@ -33,22 +36,141 @@ def transform(q_int, elements, weight):
     return f1 / f2
 
 
-def _solve_free(K, rhs, qf):
-    Kqq = K[qf][:, qf].tocsc()
-    return sspl.spsolve(Kqq, rhs[qf])
+class _HostOps:
+    """Vectors as ndarrays, K as csr_matrix, sparse direct solve."""
+
+    def __init__(self, ctx, qf):
+        self.ctx, self.qf = ctx, qf
+
+    def vec(self, a):
+        return np.array(a, dtype=np.float64).ravel()
+
+    def zeros(self):
+        return np.zeros(self.ctx.n_dof if hasattr(self.ctx, 'n_dof') else self.qf.size)
+
+    def new_ep(self):
+        return np.zeros((4, self.ctx.n_int))
+
+    def step(self, U, Ep=None, accept=False, e0=None, want=('K', 'F'), keep_K=False):
+        kw = {} if e0 is None else {'e0': e0}
+        return self.ctx.step(U, Ep, apply_plastic_strain=accept, want=want, **kw)
+
+    def solve(self, K, rhs):
+        rhs = np.asarray(rhs).ravel()
+        x = np.zeros(rhs.size)
+        x[self.qf] = sspl.spsolve(K[self.qf][:, self.qf].tocsc(), rhs[self.qf])
+        return x
+
+    def matvec(self, K, v):
+        return K @ v
+
+    def energy(self, K, v):
+        return float(np.sqrt(v @ (K @ v)))
+
+    def host(self, v):
+        return np.asarray(v)
+
+    def nodal(self, q_int, elem, weight):
+        return transform(self.host(q_int), elem, weight)
+
+    def close(self):
+        pass
 
 
-def _energy(K, v):
-    return np.sqrt(v @ (K @ v))
+class _DeviceOps:
+    """Vectors, K data, plastic strain and stresses as device tensors; `MeshContext.step_dev` writes them and
+    `KrylovSolver.pcg` solves on them.  A linear solve that breaks down or runs out of iterations yields NaNs,
+    which the drivers treat like the reference treats a NaN criterion (DP:1076): the load step is halved."""
+
+    def __init__(self, ctx, qf, rtol=1e-11, max_iter=200000):
+        import torch
+        from .solver import KrylovSolver
+        self.torch, self.ctx, self.qf = torch, ctx, qf
+        self.dev = torch.device('cuda', ctx.device)
+        self.solver = KrylovSolver(ctx, qf)
+        self.rtol, self.max_iter = rtol, max_iter
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.kd = torch.empty(ctx.nnz, **f64)
+        self.F = torch.empty(ctx.n_dof, **f64)
+        self.s = torch.empty((4, ctx.n_int), **f64)
+        self.ind = torch.empty(ctx.n_int, dtype=torch.uint8, device=self.dev)
+        self.counts = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self.tmp = torch.empty(ctx.n_dof, **f64)
+        self.pcg_iters = []
+
+    def vec(self, a):
+        return self.torch.from_numpy(np.array(a, dtype=np.float64).ravel()).to(self.dev)
+
+    def zeros(self):
+        return self.torch.zeros(self.ctx.n_dof, dtype=self.torch.float64, device=self.dev)
+
+    def new_ep(self):
+        return self.torch.zeros((4, self.ctx.n_int), dtype=self.torch.float64, device=self.dev)
+
+    def step(self, U, Ep=None, accept=False, e0=None, want=('K', 'F'), keep_K=False):
+        t = self.torch
+        st = t.cuda.current_stream(self.dev).cuda_stream
+        kd = None
+        if 'K' in want:
+            kd = t.empty(self.ctx.nnz, dtype=t.float64, device=self.dev) if keep_K else self.kd
+        self.ctx.step_dev(st, U.data_ptr(), ep=0 if Ep is None else Ep.data_ptr(), accept=accept and Ep is not None,
+                          e0=e0, s=self.s.data_ptr() if 's' in want else 0,
+                          ind_p=self.ind.data_ptr() if 'ind_p' in want else 0,
+                          k_data=0 if kd is None else kd.data_ptr(), f_out=self.F.data_ptr() if 'F' in want else 0,
+                          counts=self.counts.data_ptr())
+        out = {'K': kd, 'F': self.F, 's': self.s, 'ind_p': self.ind}
+        out = {k: v for k, v in out.items() if k in want}
+        if 's' in want or 'ind_p' in want:                     # accepting calls: the counters are logged
+            c = self.counts.cpu()
+            out['n_smooth'], out['n_apex'] = int(c[0]), int(c[1])
+        return out
+
+    def solve(self, K, rhs):
+        x = self.solver.pcg(K, rhs, rtol=self.rtol, max_iter=self.max_iter)
+        self.pcg_iters.append(self.solver.last['iters'])
+        if self.solver.last['state'] != 1:
+            x.fill_(float('nan'))
+        return x
+
+    def matvec(self, K, v):
+        return self.solver.spmv(K, v)
+
+    def energy(self, K, v):
+        self.solver.spmv(K, v, out=self.tmp)
+        return float(self.torch.sqrt(self.torch.dot(v, self.tmp)))
+
+    def host(self, v):
+        return v.cpu().numpy()
+
+    def nodal(self, q_int, elem, weight):
+        t = self.torch
+        q = q_int.contiguous()
+        out = t.empty(self.ctx.n_n, dtype=t.float64, device=self.dev)
+        self.ctx.transform_dev(t.cuda.current_stream(self.dev).cuda_stream, q.data_ptr(), out.data_ptr())
+        return out.cpu().numpy()
+
+    def close(self):
+        self.solver.close()
+
+
+def _make_ops(ctx, qf, linear_solver, pcg_rtol):
+    if linear_solver == 'direct':
+        return _HostOps(ctx, qf)
+    if linear_solver == 'pcg':
+        if not isinstance(ctx, MeshContext):
+            raise ValueError("linear_solver='pcg' needs the GPU MeshContext")
+        return _DeviceOps(ctx, qf, rtol=pcg_rtol)
+    raise ValueError("linear_solver must be 'direct' or 'pcg'")
 
 
 def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, max_steps=None, zeta_max=1.0,
-                        device=None, log=None, context_factory=None):
+                        device=None, log=None, context_factory=None, linear_solver='direct', pcg_rtol=1e-11,
+                        keep_U=True):
     """Strip-footing benchmark of Plasticity2D_DP (DP:901-1131).  `level` as in the reference
     (N = size_xy * 2**level cells per side) or `n_cells` directly.  Returns a dict with the load history
     ('zeta', 'pressure'), the accepted displacements 'U' (list of (2,n_n)), final 'Ep', counters.
     `context_factory(elements, coordinates, dhatp1, dhatp2, wf)` may supply another object with MeshContext's
-    `set_materials / step / geometry / close` (the tests drive the same loop with the CPU oracle that way)."""
+    `set_materials / step / geometry / close` (the tests drive the same loop with their CPU checker that way)."""
     t = _coerce(element_type)
     young, poisson, c0, phi = 1e7, 0.48, 450, np.pi / 9                                   # DP:910-933
     shear0 = young / (2 * (1 + poisson))
@@ -61,24 +183,21 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     n_n = coord.shape[1]
     d1, d2, wf = element_tables(t)
     ctx = (context_factory or (lambda *a: MeshContext(*a, device=device)))(elem, coord, d1, d2, wf)
-    n_int = ctx.n_int
     ctx.set_materials(shear0, bulk0, eta0, c_0)
-    K_elast = ctx.step(np.zeros(2 * n_n), want=('K',))['K']                               # DP:977
-    _, _, weight, _ = ctx.geometry()
     qf = Q.flatten(order='F')
+    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol)
+    K_elast = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                        # DP:977
+    _, _, weight, _ = ctx.geometry()
 
     d_zeta = 1 / 1000                                                                     # DP:989-994
     d_zeta_min = d_zeta / 1300
     d_zeta_old = d_zeta
     zeta_old = 0.0
-    Ud = -d_zeta * mesh['dirichlet_nodes']                                                # DP:997-1004
-    f = -(K_elast @ Ud.flatten(order='F'))
-    U_it = Ud.flatten(order='F')
-    U_it[qf] = _solve_free(K_elast, f, qf)
-    dU = np.zeros(2 * n_n)
-    U = np.zeros(2 * n_n)
+    Ud = ops.vec((-d_zeta * mesh['dirichlet_nodes']).flatten(order='F'))                  # DP:997-1004
+    U_it = Ud + ops.solve(K_elast, -ops.matvec(K_elast, Ud))
+    U = ops.zeros()
     U_old = -U_it
-    Ep_old = np.zeros((4, n_int))
+    Ep_old = ops.new_ep()
     pressure_old = 0.0
     hist = {'zeta': [], 'pressure': [], 'U': [], 'counts': [], 'n_calls': 0, 'newton_its': []}
     criterion = None
@@ -86,12 +205,12 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
         zeta = zeta_old + d_zeta                                                          # DP:1031
         its = 0
         for _ in range(25):                                                               # DP:1040
-            r = ctx.step(U_it, Ep_old, apply_plastic_strain=False, want=('K', 'F'))       # DP:1043-1058
+            r = ops.step(U_it, Ep_old, accept=False, want=('K', 'F'))                     # DP:1043-1058
             hist['n_calls'] += 1
             its += 1
-            dU[qf] = _solve_free(r['K'], -r['F'], qf)                                     # DP:1062-1066
+            dU = ops.solve(r['K'], -r['F'])                                               # DP:1062-1066
             U_new = U_it + dU
-            q1, q2, q3 = _energy(K_elast, dU), _energy(K_elast, U_it), _energy(K_elast, U_new)   # DP:1072-1074
+            q1, q2, q3 = ops.energy(K_elast, dU), ops.energy(K_elast, U_it), ops.energy(K_elast, U_new)   # DP:1072-1074
             criterion = q1 / (q2 + q3)
             if np.isnan(criterion):                                                       # DP:1076
                 break
@@ -101,15 +220,16 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
         if criterion < 1e-10:                                                             # DP:1091
             U_old = U
             U = U_it
-            r = ctx.step(U, Ep_old, apply_plastic_strain=True, want=('s',))               # DP:1095-1098
+            r = ops.step(U, Ep_old, accept=True, want=('s',))                             # DP:1095-1098
             hist['n_calls'] += 1
             zeta_old = zeta
             d_zeta_old = d_zeta
-            pressure_arr = transform(r['s'][1, :], elem, weight)                          # DP:1105
+            pressure_arr = ops.nodal(r['s'][1, :], elem, weight)                          # DP:1105
             pressure = -np.mean(pressure_arr[q_nd]) / c0
             hist['zeta'].append(zeta)
             hist['pressure'].append(pressure)
-            hist['U'].append(U.reshape((2, -1), order='F').copy())
+            if keep_U:
+                hist['U'].append(ops.host(U).reshape((2, -1), order='F').copy())
             hist['counts'].append((r['n_smooth'], r['n_apex']))
             hist['newton_its'].append(its)
             if log:
@@ -126,13 +246,17 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
             break
         if max_steps is not None and len(hist['zeta']) >= max_steps:
             break
-    hist['Ep'] = Ep_old
+    hist['Ep'] = ops.host(Ep_old)
+    hist['U_last'] = ops.host(U).reshape((2, -1), order='F').copy()
     hist['mesh'] = mesh
+    hist['pcg_iters'] = getattr(ops, 'pcg_iters', None)
+    ops.close()
     ctx.close()
     return hist
 
 
-def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(0, 40), device=None, log=None):
+def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(0, 40), device=None, log=None,
+                     linear_solver='direct', pcg_rtol=1e-11):
     """TSX tunnel excavation (TSX:1637-1832) on a given mesh (`coords` (2,n_n), `elem` (n_p,n_e) 0-based; the
     reference reads coord.csv / elem.csv and, for P2/P4, adds midpoints first).  Returns the history of the
     monitored displacement, plastic-point counts and accepted displacements."""
@@ -153,37 +277,35 @@ def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(
     Q[1, coords[1, :] < -49.99] = 0
     Q[1, coords[1, :] > 49.99] = 0
     qf = Q.flatten(order='F')
-    n_n = coords.shape[1]
     d1, d2, wf = element_tables(t)
     ctx = MeshContext(elem, coords, d1, d2, wf, device=device)
     n_int = ctx.n_int
     assert n_int == elem.shape[1] * ELEMENT_SHAPE[t][1]
     ctx.set_materials(shear0, bulk0, eta0, c_0)
-    K = ctx.step(np.zeros(2 * n_n), want=('K',))['K']                                     # TSX:1722
+    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol)
+    K = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                              # TSX:1722
     _, F0 = ctx.assemble(None, s0 * np.ones((1, n_int)))                                   # TSX:1737
 
     d_zeta = 1 / n_load_steps                                                             # TSX:1730-1735
     d_zeta_min = d_zeta / 10
     d_zeta_old = d_zeta
     zeta_old = 0.0
-    U_elast = np.zeros(2 * n_n)
-    U_elast[qf] = _solve_free(K, -F0, qf)                                                 # TSX:1748
+    U_elast = ops.solve(K, ops.vec(-F0))                                                  # TSX:1748
     U_it = d_zeta * U_elast
-    dU = np.zeros(2 * n_n)
-    U = np.zeros(2 * n_n)
+    U = ops.zeros()
     U_old = -U_it
-    Ep_old = np.zeros((4, n_int))
+    Ep_old = ops.new_ep()
     hist = {'zeta': [], 'displ': [], 'n_plast': [], 'U': [], 'n_calls': 0}
     criterion = None
     while True:
         zeta = zeta_old + d_zeta
         e0 = zeta * init_strain                                                           # TSX:1765
         for _ in range(25):
-            r = ctx.step(U_it, Ep_old, e0=e0, want=('K', 'F'))                            # TSX:1771-1778
+            r = ops.step(U_it, Ep_old, e0=e0, want=('K', 'F'))                            # TSX:1771-1778
             hist['n_calls'] += 1
-            dU[qf] = _solve_free(r['K'], -r['F'], qf)                                     # TSX:1781
+            dU = ops.solve(r['K'], -r['F'])                                               # TSX:1781
             U_new = U_it + dU
-            criterion = _energy(K, dU) / (_energy(K, U_it) + _energy(K, U_new))           # TSX:1788-1792
+            criterion = ops.energy(K, dU) / (ops.energy(K, U_it) + ops.energy(K, U_new))  # TSX:1788-1792
             if np.isnan(criterion):
                 break
             U_it = U_new
@@ -192,15 +314,15 @@ def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(
         if criterion < 1e-10:                                                             # TSX:1804
             U_old = U
             U = U_it
-            r = ctx.step(U, Ep_old, e0=e0, want=('ind_p',))          # accept WITHOUT apply_plastic_strain (C7)
+            r = ops.step(U, Ep_old, e0=e0, want=('ind_p',))          # accept WITHOUT apply_plastic_strain (C7)
             hist['n_calls'] += 1
-            Ep_old = np.zeros((4, n_int))                            # 'ep' of a non-accepting call, TSX:1809
+            Ep_old = ops.new_ep()                                    # 'ep' of a non-accepting call, TSX:1809
             zeta_old = zeta
             d_zeta_old = d_zeta
-            Um = U.reshape((2, -1), order='F')
+            Um = ops.host(U).reshape((2, -1), order='F')
             hist['zeta'].append(zeta)
             hist['displ'].append(Um[monitor])
-            hist['n_plast'].append(int(r['ind_p'].sum()))
+            hist['n_plast'].append(int(ops.host(r['ind_p']).astype(bool).sum()))
             hist['U'].append(Um.copy())
             if log:
                 log(f'zeta={zeta:.6g} U{monitor}={Um[monitor]:.16g} n_plast={hist["n_plast"][-1]}')
@@ -213,5 +335,7 @@ def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(
             break
     hist['F0'] = F0.reshape((2, -1), order='F')
     hist['Q'] = Q
+    hist['pcg_iters'] = getattr(ops, 'pcg_iters', None)
+    ops.close()
     ctx.close()
     return hist

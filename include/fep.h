@@ -173,6 +173,37 @@ int fep_gather_f64(int device_id, void* stream, int64_t n, const double* src_d, 
 int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* src_idx_d,
                     const int32_t* dst_idx_d, double* dst_d);
 
+/* ---- callers of the hot path ----------------------------------------------------------------
+ * transform (DP:760-816): integration-point values (n_int) -> nodal values (n_n), mean over the points of the
+ * adjacent elements weighted with quadrature weight * |det J| (the footing pressure that steers the load step,
+ * DP:1105). */
+int fep_transform_dev(fep_ctx* ctx, void* stream, const double* q_int_d, double* q_node_d);
+int fep_transform_host(fep_ctx* ctx, const double* q_int_h, double* q_node_h);
+
+/* Linear solve of a Newton iterate, K[Q][:,Q] dU[Q] = b[Q]  (np.linalg.solve on the dense boolean-masked block at
+ * DP:1062-1066 / TSX:1781).  Preconditioned conjugate gradients (2x2 node-block Jacobi) entirely on
+ * the device; K is the `data` array fep_step_dev wrote, on the context's CSR pattern.
+ *
+ *   fep_solver_create   pattern = fep_ctx_pattern_host (checked: rows 2n, 2n+1 share their columns, which come in
+ *                       pairs 2m, 2m+1 -> FEP_EINVAL otherwise); free_dof_h (2 n_n) is Q in DOF order, non-zero = free
+ *   fep_solver_sizes    {n_n, n_dof, nnz, n_free}
+ *   fep_solver_spmv_dev y = K x (masked != 0: y = Q K x, x must then be 0 on the constrained DOFs); x != y
+ *   fep_solver_pcg_dev  x = 0 on entry is implied; iterates until |r| <= rtol |b[Q]| (recursive residual), at most
+ *                       max_iter iterations; the host looks at the device-side state every check_every iterations
+ *                       (<= 0: 50) and the iterate is frozen on the device at the iteration that met the test.
+ *                       *state_out: 0 = max_iter reached, 1 = converged, 2 = breakdown (K[Q][:,Q] not positive
+ *                       definite or non-finite values); x is 0 on constrained DOFs.  Synchronises `stream`. */
+typedef struct fep_solver fep_solver;
+int fep_solver_create(fep_solver** solver_out, int device_id, int64_t n_n, const int32_t* indptr_h,
+                      const int32_t* indices_h, const uint8_t* free_dof_h);
+int fep_solver_destroy(fep_solver* solver);
+int fep_solver_sizes(const fep_solver* solver, int64_t sizes[4]);
+int fep_solver_spmv_dev(fep_solver* solver, void* stream, const double* k_data_d, const double* x_d, double* y_d,
+                        int masked);
+int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d, const double* b_d, double* x_d,
+                       double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
+                       int* state_out);
+
 /* ---- in-situ kernel timing (bench.py's roofline figure) --------------------------------
  * Between fep_ctx_profile_begin and fep_ctx_profile_end every fep_step_dev / fep_assemble_dev call
  * brackets each of its kernels with HIP events on the launch stream (the kernels run in their real

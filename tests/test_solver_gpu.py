@@ -1,0 +1,140 @@
+"""
+GPU Krylov solver and nodal averaging against SciPy on the same matrices.
+
+Tolerances: PCG runs to a relative residual of 1e-12, the solution is compared with SuperLU's to 1e-8
+relative (condition number of the footing problem ~1e5..1e6); SpMV and `transform` to 1e-13.
+"""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as sspl
+
+from conftest import dp_materials, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(fep, et, n, plastic):
+    mesh = fep.square_mesh(n, et, 10)
+    ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'], element_type=et)
+    ctx.set_materials(*dp_materials(ctx.n_int))
+    rng = np.random.default_rng(3)
+    U, Ep = np.zeros(ctx.n_dof), np.zeros((4, ctx.n_int))
+    if plastic:                       # tangent at a converged iterate a few load steps into the plastic regime
+        h = fep.solve_strip_footing(et, n_cells=n, max_steps=4)
+        U, Ep = h['U'][-1], h['Ep']
+    r = ctx.step(U, Ep, want=('K', 'F'))
+    qf = mesh['Q'].flatten(order='F')
+    return mesh, ctx, r, qf, rng
+
+
+@pytest.mark.parametrize('et,n,plastic', [('P1', 12, False), ('P1', 40, True), ('P2', 8, True), ('Q1', 16, True),
+                                          ('Q2', 6, False)])
+def test_pcg_matches_sparse_direct(fep, et, n, plastic):
+    mesh, ctx, r, qf, rng = _problem(fep, et, n, plastic)
+    if plastic:
+        assert r['n_smooth'] + r['n_apex'] > 0
+    K = r['K']
+    b = rng.normal(size=ctx.n_dof)
+    sol = fep.KrylovSolver(ctx, qf)
+    assert (sol.n_n, sol.n_dof, sol.nnz, sol.n_free) == (ctx.n_n, ctx.n_dof, ctx.nnz, int(qf.sum()))
+    x = sol.solve_host(K, b, rtol=1e-12)
+    assert sol.last['state'] == 1 and 0 < sol.last['iters'] < 20000 and sol.last['relres'] <= 1e-12
+    ref = np.zeros(ctx.n_dof)
+    ref[qf] = sspl.spsolve(K[qf][:, qf].tocsc(), b[qf])
+    assert np.all(x[~qf] == 0.0)
+    assert relerr(x, ref) <= 1e-8
+    res = (K @ x - b)[qf]
+    assert np.linalg.norm(res) <= 1e-10 * np.linalg.norm(b[qf])       # true residual, not the recursive one
+    # reproducible bit for bit
+    assert np.array_equal(x, sol.solve_host(K, b, rtol=1e-12))
+    sol.close()
+    ctx.close()
+
+
+def test_spmv_matches_scipy(fep):
+    import torch
+    mesh, ctx, r, qf, rng = _problem(fep, 'P2', 7, True)
+    K = r['K']
+    sol = fep.KrylovSolver(ctx, qf)
+    x = rng.normal(size=ctx.n_dof)
+    y = sol.spmv(K.data, x).cpu().numpy()
+    assert relerr(y, K @ x) <= 1e-13
+    xm = np.where(qf, x, 0.0)
+    ym = sol.spmv(K.data, xm, masked=True).cpu().numpy()
+    assert relerr(ym, np.where(qf, K @ xm, 0.0)) <= 1e-13 and np.all(ym[~qf] == 0.0)
+    assert torch.cuda.is_available()
+    sol.close()
+    ctx.close()
+
+
+def test_pcg_edge_cases(fep):
+    mesh, ctx, r, qf, rng = _problem(fep, 'P1', 10, False)
+    K = r['K']
+    sol = fep.KrylovSolver(ctx, qf)
+    # zero right-hand side on the free DOFs: x = 0 without iterating
+    b0 = np.where(qf, 0.0, 7.0)
+    x = sol.solve_host(K, b0)
+    assert sol.last == {'iters': 0, 'relres': 0.0, 'state': 1} and np.all(x == 0.0)
+    # a negative definite matrix is reported as breakdown, not iterated on
+    x = sol.solve_host(-K.data, rng.normal(size=ctx.n_dof))
+    assert sol.last['state'] == 2
+    # iteration cap
+    x = sol.solve_host(K, rng.normal(size=ctx.n_dof), rtol=1e-14, max_iter=3, check_every=2)
+    assert sol.last['state'] == 0 and sol.last['iters'] == 3 and np.isfinite(x).all()
+    # everything constrained
+    s2 = fep.KrylovSolver(ctx, np.zeros(ctx.n_dof, dtype=bool))
+    assert np.all(s2.solve_host(K, rng.normal(size=ctx.n_dof)) == 0.0) and s2.last['state'] == 1
+    s2.close()
+    sol.close()
+    ctx.close()
+
+
+def test_solver_rejects_foreign_patterns(fep):
+    ip = np.array([0, 2, 3, 5, 7], dtype=np.int32)                 # rows 0 and 1 of node 0 differ in length
+    ix = np.array([0, 1, 0, 2, 3, 2, 3], dtype=np.int32)
+    with pytest.raises(fep.FepError, match='invalid argument'):
+        fep.KrylovSolver((ip, ix), np.ones(4, dtype=bool), device=0)
+    with pytest.raises(ValueError):
+        fep.KrylovSolver((ip, ix), np.ones(3, dtype=bool), device=0)
+
+
+@pytest.mark.parametrize('et', ['P1', 'P2', 'Q2'])
+def test_transform_on_gpu_matches_host_restatement(fep, et):
+    mesh = fep.square_mesh(9, et, 10)
+    ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'], element_type=et)
+    _, _, weight, _ = ctx.geometry()
+    q = np.random.default_rng(1).normal(size=ctx.n_int)
+    assert relerr(ctx.transform(q), fep.transform(q, mesh['elements'], weight)) <= 1e-13
+    ctx.close()
+
+
+def test_footing_driver_with_gpu_solver_reproduces_reference_trace(fep):
+    """Same pins as the SuperLU-driven run (test_newton_gpu): the iterate never leaves the device here."""
+    from conftest import load_golden
+    g = load_golden('dp_p1_level1_trace')
+    h = fep.solve_strip_footing('P1', level=1, linear_solver='pcg')
+    assert len(h['zeta']) == 16 and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
+    assert np.abs(np.array(h['pressure'][:15]) - g['pressure'][1:16]).max() <= 1e-8 * np.abs(g['pressure']).max()
+    for k in range(16):
+        assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-9, k
+    assert h['counts'][-1] == (599, 171)
+    assert relerr(h['Ep'], g['Ep_final']) <= 1e-8
+    assert h['pcg_iters'] and max(h['pcg_iters']) < 5000
+
+
+def test_tsx_driver_with_gpu_solver(fep):
+    from conftest import load_golden
+    g = load_golden('tsx')
+    h = fep.solve_tsx_tunnel(g['coord'], g['elem'], 'P1', linear_solver='pcg')
+    assert len(h['zeta']) == 17 and h['n_plast'] == [0] * 13 + [1, 1, 2, 3]
+    assert relerr(h['U'][-1], g['p1_U_final']) <= 1e-9
+    assert abs(h['displ'][-1] - (-0.0019794496707526746)) <= 1e-9 * 0.0019794496707526746
+
+
+def test_footing_48_cells_pcg_vs_direct(fep):
+    a = fep.solve_strip_footing('P1', n_cells=48, max_steps=6)
+    b = fep.solve_strip_footing('P1', n_cells=48, max_steps=6, linear_solver='pcg')
+    assert a['zeta'] == b['zeta'] and a['counts'] == b['counts']
+    for k in range(6):
+        assert relerr(a['U'][k], b['U'][k]) <= 1e-9, k
+    assert np.abs(np.array(a['pressure']) - np.array(b['pressure'])).max() <= 1e-8 * max(a['pressure'])
