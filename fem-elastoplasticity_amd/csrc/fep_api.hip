@@ -21,6 +21,7 @@ struct fep_ctx {
     int n_p = 0, n_q = 0;
     int64_t n_e = 0, n_n = 0, n_int = 0, n_dof = 0, nnz = 0, n_blk = 0, n_contrib = 0;
     bool have_materials = false;
+    MatU matu{};                                        // homogeneous-material fast path (arrays not read)
     // device, static
     int32_t* elem = nullptr;
     double *coords = nullptr, *dh1 = nullptr, *dh2 = nullptr, *wf = nullptr;
@@ -639,10 +640,21 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
     CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
     if (!c->p1_node && !c->gn) {
-        CK(upload(&c->perm, S.perm.data(), (int64_t)S.perm.size()));
+        {   // element_kernel stores half of the symmetric K_e: re-address the contributions (block, transposed)
+            std::vector<int32_t> perm_sym(S.perm.size());
+            for (size_t i = 0; i < S.perm.size(); ++i) {
+                const int64_t v = S.perm[i];
+                const int ab = (int)(v / n_e);
+                const int64_t e = v - (int64_t)ab * n_e;
+                int idx; bool tr;
+                sym_block_index(n_p, ab / n_p, ab % n_p, idx, tr);
+                perm_sym[i] = (int32_t)(2 * ((int64_t)idx * n_e + e) + (tr ? 1 : 0));
+            }
+            CK(upload(&c->perm, perm_sym.data(), (int64_t)perm_sym.size()));
+        }
         CK(upload(&c->tstart, tstart_all.data(), (int64_t)tstart_all.size()));
         c->n_wg_p1 = (int)tstart_all.size() - 1;
-        CK(dmalloc(&c->Kc, 4 * c->n_contrib));
+        CK(dmalloc(&c->Kc, 4 * (int64_t)sym_block_count(n_p) * n_e));
         CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
         int eb = 1;
         switch (elem_type) {
@@ -708,6 +720,11 @@ extern "C" int fep_ctx_set_materials_host(fep_ctx* c, const double* shear_h, con
     HIP_TRY(hipMemcpy(c->eta, eta_h, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->c, c_h, nb, hipMemcpyHostToDevice));
     c->have_materials = true;
+    // every parameter constant over the mesh (the reference's demos): the kernels skip the four arrays
+    bool uni = std::getenv("FEP_NO_UNIFORM") == nullptr;
+    for (int64_t k = 1; uni && k < c->n_int; ++k)
+        uni = shear_h[k] == shear_h[0] && bulk_h[k] == bulk_h[0] && eta_h[k] == eta_h[0] && c_h[k] == c_h[0];
+    c->matu = MatU{shear_h[0], bulk_h[0], eta_h[0], c_h[0], uni ? 1 : 0};
     return FEP_OK;
 }
 
@@ -745,7 +762,7 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
     constexpr int EB = ElemCfg<NP, NQ>::EB;
     static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
     hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U>), dim3(grid_for(c->n_e, EB)), dim3(kBlock), 0, st,
-                       c->n_e, c->elem, c->dphi1, c->dphi2, c->weight, u, e0, ep, c->shear, c->bulk, c->eta, c->c,
+                       c->n_e, c->elem, c->dphi1, c->dphi2, c->weight, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu,
                        accept, eout, s, ds, indp, blk_counts, Kc, fe);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
@@ -864,7 +881,7 @@ template <int NP, int NQ>
 static int launch_point(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept, double* eout,
                         double* s, double* ds, uint8_t* indp, uint2* blk) {
     hipLaunchKernelGGL((point_kernel<NP, NQ>), dim3(grid_for(c->n_int, kBlock)), dim3(kBlock), 0, st, c->n_e, c->elem,
-                       c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear, c->bulk, c->eta, c->c, accept, eout, s, ds, indp, blk);
+                       c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }
@@ -891,7 +908,7 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
         }
         FEP_TRY(prof_mark(c, st));
         hipLaunchKernelGGL(p1_point_kernel, dim3(grid_for(c->n_e, kBlock)), dim3(kBlock), 0, st,
-                           c->n_e, c->elem, c->xy, c->p1tab, u_d, e0, ep_prev_d, c->shear, c->bulk, c->eta, c->c, accept,
+                           c->n_e, c->elem, c->xy, c->p1tab, u_d, e0, ep_prev_d, c->shear, c->bulk, c->eta, c->c, c->matu, accept,
                            e_out_d, s_d, ds_d, ind_p_d, blk);
         HIP_TRY(hipGetLastError());
         bool counted = false;

@@ -237,12 +237,27 @@ geometry_kernel(int64_t n_e, int64_t n_n, const int32_t* __restrict__ elem, cons
 //
 //  phase 1 (one lane per integration point): strain from U (a1), return map (a2), results to
 //          HBM (coalesced over k) and w*DS, w*S, dphi staged in LDS;
-//  phase 2 (one lane per (element, local node a)): rows 2a, 2a+1 of K_e = sum_q B^T (w DS) B (a3, a4)
-//          and of f_e = sum_q B^T (w S) (a5), written as 2x2 node-pair blocks
-//          Kc[((a*NP+b)*n_e + e)*4 + 2i+j] and pairs fe[(a*n_e+e)*2 + i].
+//  phase 2 (one lane per (element, local node a)): K_e = sum_q B^T (w DS) B (a3, a4) is symmetric (DS is), so
+//          only half of its 2x2 node-pair blocks are computed and stored: the lane of node a holds the blocks
+//          (a, b = (a+j) mod NP), j = 0..NP/2 (for even NP the j = NP/2 block only when a < NP/2) at
+//          Kc[((j*NP+a)*n_e + e)*4 + 2i+jj]; the block (b, a) is its transpose (sym_block_index below).
+//          f_e = sum_q B^T (w S) (a5) as pairs fe[(a*n_e+e)*2 + i].
 //
 //  FROM_U = true : inputs U (+ ep, materials);  FROM_U = false : inputs DS, S (assembly only).
 // ---------------------------------------------------------------------------------------
+// Homogeneous material (the reference's demos: one constant per parameter, DP:972-984): the four per-point
+// arrays are not read at all.  `on` is set by fep_ctx_set_materials_host when every array is constant.
+struct MatU { double shear, bulk, eta, c; int on; };
+
+// Where element_kernel keeps the block (a, b) of K_e: index of the stored block and whether it is the transpose.
+inline __host__ __device__ void sym_block_index(int n_p, int a, int b, int& idx, bool& transposed) {
+    const int j = b >= a ? b - a : b - a + n_p;
+    const bool direct = 2 * j < n_p || (2 * j == n_p && a < n_p / 2);
+    if (direct) { idx = j * n_p + a; transposed = false; }
+    else { idx = (n_p - j) * n_p + b; transposed = true; }
+}
+inline __host__ __device__ int sym_block_count(int n_p) { return (n_p / 2 + 1) * n_p; }   // upper bound on idx + 1
+
 template <int NP, int NQ> struct ElemCfg {
     static constexpr int maxpq = NP > NQ ? NP : NQ;
     static constexpr int EB = (kBlock / maxpq) >= 64 ? 64 : ((kBlock / maxpq) >= 32 ? 32 : (kBlock / maxpq));
@@ -257,7 +272,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                // FROM_U inputs
                const double* __restrict__ U, E0 e0, double* __restrict__ ep,
                const double* __restrict__ shear, const double* __restrict__ bulk,
-               const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+               const double* __restrict__ eta, const double* __restrict__ cc, MatU mu, int accept,
                // outputs of phase 1 (FROM_U) or inputs (!FROM_U)
                double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
                uint2* blk_counts,
@@ -265,6 +280,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                double* __restrict__ Kc, double* __restrict__ fe) {
     using C = ElemCfg<NP, NQ>;
     constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
+    constexpr int NJ = NP / 2 + 1;                   // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
     __shared__ double d1s[NP][NPTS], d2s[NP][NPTS];
     __shared__ double Ds[6][NPTS], Ss[3][NPTS];
     __shared__ int32_t nds[NP][EB];
@@ -303,7 +319,9 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             }
             double p[4] = {0.0, 0.0, 0.0, 0.0};
             if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
-            branch = dp_return_map(ev, e0.v, p, shear[k], bulk[k], eta[k], cc[k], accept != 0, s, d);
+            const double m_sh = mu.on ? mu.shear : shear[k], m_bu = mu.on ? mu.bulk : bulk[k];
+            const double m_eta = mu.on ? mu.eta : eta[k], m_c = mu.on ? mu.c : cc[k];
+            branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, accept != 0, s, d);
             store_point(k, n_int, s, d, branch, S, DS, indp);
             if (Eout) { Eout[k] = ev[0]; Eout[n_int + k] = ev[1]; Eout[2 * n_int + k] = ev[2]; }
             if (accept && ep && branch) {
@@ -333,9 +351,9 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         const int a = i / EB, el = i - a * EB;
         if (el >= nel) continue;
         const int64_t e = e0blk + el;
-        double k0[2 * NP], k1[2 * NP];
+        double kk[NJ][4];
 #pragma unroll
-        for (int j = 0; j < 2 * NP; ++j) { k0[j] = 0.0; k1[j] = 0.0; }
+        for (int j = 0; j < NJ; ++j) { kk[j][0] = 0.0; kk[j][1] = 0.0; kk[j][2] = 0.0; kk[j][3] = 0.0; }
         double f0 = 0.0, f1 = 0.0;
         for (int q = 0; q < NQ; ++q) {
             const int li = el * NQS + q;
@@ -348,20 +366,22 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
             const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
 #pragma unroll
-            for (int b = 0; b < NP; ++b) {
+            for (int j = 0; j < NJ; ++j) {
+                const int b = a + j >= NP ? a + j - NP : a + j;
                 const double b1 = d1s[b][li], b2 = d2s[b][li];
-                k0[2 * b]     += r00 * b1 + r02 * b2;
-                k0[2 * b + 1] += r01 * b2 + r02 * b1;
-                k1[2 * b]     += r10 * b1 + r12 * b2;
-                k1[2 * b + 1] += r11 * b2 + r12 * b1;
+                kk[j][0] += r00 * b1 + r02 * b2;
+                kk[j][1] += r01 * b2 + r02 * b1;
+                kk[j][2] += r10 * b1 + r12 * b2;
+                kk[j][3] += r11 * b2 + r12 * b1;
             }
         }
         if (Kc) {
 #pragma unroll
-            for (int b = 0; b < NP; ++b) {
-                double2* dst = reinterpret_cast<double2*>(Kc + ((int64_t)(a * NP + b) * n_e + e) * 4);
-                dst[0] = make_double2(k0[2 * b], k0[2 * b + 1]);
-                dst[1] = make_double2(k1[2 * b], k1[2 * b + 1]);
+            for (int j = 0; j < NJ; ++j) {
+                if (NP % 2 == 0 && j == NP / 2 && a >= NP / 2) continue;     // held by the lane of node a - NP/2
+                double2* dst = reinterpret_cast<double2*>(Kc + ((int64_t)(j * NP + a) * n_e + e) * 4);
+                dst[0] = make_double2(kk[j][0], kk[j][1]);
+                dst[1] = make_double2(kk[j][2], kk[j][3]);
             }
         }
         if (fe) *reinterpret_cast<double2*>(fe + ((int64_t)a * n_e + e) * 2) = make_double2(f0, f1);
@@ -371,7 +391,8 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 // ---------------------------------------------------------------------------------------
 // Numeric COO -> CSR phase: one lane per node-pair block (row node n, neighbour slot s).
 // Deterministic: contributions are summed in the fixed order of `perm` (no atomics).
-//   segptr[n_blk+1], perm[...] = (a*NP+b)*n_e + e,  meta[blk] = (deg(n) << 16) | (diag << 15) | s
+//   segptr[n_blk+1], perm[...] = 2*(sym_block_index(a,b)*n_e + e) + transposed,
+//   meta[blk] = (deg(n) << 16) | (diag << 15) | s
 //   CSR data: row 2n+i starts at 4*nptr[n] + i*2*deg, entry (slot s, comp j) at + 2s + j.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -392,9 +413,11 @@ csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t
         const uint32_t m = meta[sb];
         double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
         for (int32_t t = beg; t < end; ++t) {
-            const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)perm[t] * 4);
+            const int32_t pv = perm[t];                         // (stored block index) * 2 + transposed
+            const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(pv >> 1) * 4);
             const double2 r0 = src[0], r1 = src[1];
-            a00 += r0.x; a01 += r0.y; a10 += r1.x; a11 += r1.y;
+            const bool tr = pv & 1;
+            a00 += r0.x; a01 += tr ? r1.x : r0.y; a10 += tr ? r0.y : r1.x; a11 += r1.y;
         }
         const int sl = (int)(m & 0x7fffu), deg = (int)(m >> 16);
         const int rel = 2 * (int)threadIdx.x - sl;          // (CSR position - 4*sb0) / 2
@@ -483,7 +506,7 @@ __global__ void __launch_bounds__(kBlock)
 p1_point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __restrict__ xy, P1Tab tab,
                 const double* __restrict__ U, E0 e0, double* __restrict__ ep,
                 const double* __restrict__ shear, const double* __restrict__ bulk,
-                const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+                const double* __restrict__ eta, const double* __restrict__ cc, MatU mu, int accept,
                 double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS,
                 uint8_t* __restrict__ indp, uint2* blk_counts) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -505,7 +528,9 @@ p1_point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __r
         double p[4] = {0.0, 0.0, 0.0, 0.0};
         if (ep) { p[0] = ep[e]; p[1] = ep[n_e + e]; p[2] = ep[2 * n_e + e]; p[3] = ep[3 * n_e + e]; }
         double s[4], d[6];
-        branch = dp_return_map(ev, e0.v, p, shear[e], bulk[e], eta[e], cc[e], accept != 0, s, d);
+        const double m_sh = mu.on ? mu.shear : shear[e], m_bu = mu.on ? mu.bulk : bulk[e];
+        const double m_eta = mu.on ? mu.eta : eta[e], m_c = mu.on ? mu.c : cc[e];
+        branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, accept != 0, s, d);
         store_point(e, n_e, s, d, branch, S, DS, indp);
         if (Eout) { Eout[e] = ev[0]; Eout[n_e + e] = ev[1]; Eout[2 * n_e + e] = ev[2]; }
         if (accept && ep && branch) { ep[e] = p[0]; ep[n_e + e] = p[1]; ep[2 * n_e + e] = p[2]; ep[3 * n_e + e] = p[3]; }
@@ -818,7 +843,7 @@ point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __rest
              const double* __restrict__ dh1, const double* __restrict__ dh2, const double* __restrict__ wf,
              const double* __restrict__ U, E0 e0, double* __restrict__ ep,
              const double* __restrict__ shear, const double* __restrict__ bulk,
-             const double* __restrict__ eta, const double* __restrict__ cc, int accept,
+             const double* __restrict__ eta, const double* __restrict__ cc, MatU mu, int accept,
              double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS,
              uint8_t* __restrict__ indp, uint2* blk_counts) {
     __shared__ double t1[NP * NQ], t2[NP * NQ], tw[NQ];
@@ -848,7 +873,9 @@ point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __rest
         double p[4] = {0.0, 0.0, 0.0, 0.0};
         if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
         double s[4], d[6];
-        branch = dp_return_map(ev, e0.v, p, shear[k], bulk[k], eta[k], cc[k], accept != 0, s, d);
+        const double m_sh = mu.on ? mu.shear : shear[k], m_bu = mu.on ? mu.bulk : bulk[k];
+        const double m_eta = mu.on ? mu.eta : eta[k], m_c = mu.on ? mu.c : cc[k];
+        branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, accept != 0, s, d);
         store_point(k, n_int, s, d, branch, S, DS, indp);
         if (Eout) { Eout[k] = ev[0]; Eout[n_int + k] = ev[1]; Eout[2 * n_int + k] = ev[2]; }
         if (accept && ep && branch) { ep[k] = p[0]; ep[n_int + k] = p[1]; ep[2 * n_int + k] = p[2]; ep[3 * n_int + k] = p[3]; }

@@ -294,7 +294,7 @@ def test_el_p1_K_pins(fep, level, nnz, trace, frob):
 
 # ---- mid size vs oracle, every element type ------------------------------------------------
 @pytest.mark.parametrize('t,N', [('P1', 60), ('P2', 24), ('Q1', 40), ('Q2', 20)])
-def test_hot_path_mid_size_vs_oracle(fep, t, N):
+def test_hot_path_mid_size_vs_oracle(fep, t, N, heterogeneous=False):
     rng = np.random.default_rng(5)
     mesh = fep.square_mesh(N, t, 10)
     elem, coord = mesh['elements'], mesh['coordinates'].copy()
@@ -303,6 +303,8 @@ def test_hot_path_mid_size_vs_oracle(fep, t, N):
     d1, d2, wf = fep.element_tables(t)
     n_int = elem.shape[1] * NQ[t]
     sh, bu, eta, c = dp_materials(n_int)
+    if heterogeneous:                 # per-point parameters (the kernels' array path; constants take a fast path)
+        sh, bu, eta, c = [v * rng.uniform(0.8, 1.25, n_int) for v in (sh, bu, eta, c)]
     x, y = coord
     U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
     U += rng.normal(0, 3e-6, size=U.shape)
@@ -323,6 +325,30 @@ def test_hot_path_mid_size_vs_oracle(fep, t, N):
     diff = (r['K'] - K_t)
     assert np.abs(diff.data).max() <= TOL_K * np.abs(K_t.data).max()
     assert relerr(r['F'], F) <= TOL_K
+
+
+@pytest.mark.parametrize('t,N', [('P1', 60), ('P2', 20), ('Q1', 30), ('Q2', 12)])
+def test_heterogeneous_materials_vs_oracle(fep, t, N):
+    test_hot_path_mid_size_vs_oracle(fep, t, N, heterogeneous=True)
+
+
+def test_constant_materials_fast_path_is_bitwise_the_array_path(fep, monkeypatch):
+    mesh = fep.square_mesh(30, 'P2', 10)
+    n_int = mesh['elements'].shape[1] * 7
+    x, y = mesh['coordinates']
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('FEP_NO_UNIFORM', '1')
+        ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
+        ctx.set_materials(*dp_materials(n_int))
+        res.append(ctx.step(U, np.zeros((4, n_int)), want=('s', 'ds', 'K', 'F')))
+        ctx.close()
+    assert res[0]['n_smooth'] > 0
+    for k in ('s', 'ds', 'F'):
+        assert np.array_equal(res[0][k], res[1][k])
+    assert np.array_equal(res[0]['K'].data, res[1]['K'].data)
 
 
 # ---- full benchmark size: properties (the reference cannot run here: DP:714 needs n_apex^2 memory) ----
