@@ -21,6 +21,7 @@ struct fep_ctx {
     int n_p = 0, n_q = 0;
     int64_t n_e = 0, n_n = 0, n_int = 0, n_dof = 0, nnz = 0, n_blk = 0, n_contrib = 0;
     bool have_materials = false;
+    bool elem_geo = true;                               // element_kernel: geometry from coordinates instead of the dphi arrays
     MatU matu{};                                        // homogeneous-material fast path (arrays not read)
     // device, static
     int32_t* elem = nullptr;
@@ -564,9 +565,6 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         }
         CK(dmalloc(&c->geo, 8 * n_e));
         {
-            std::vector<double> xy(2 * (size_t)n_n);
-            for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
-            CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
             for (int a = 0; a < 3; ++a) { c->p1tab.h1[a] = dhatp1_h[a]; c->p1tab.h2[a] = dhatp2_h[a]; }
             c->p1tab.wf = wf_h[0];
         }
@@ -630,11 +628,17 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
             CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
             CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
             CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
-            std::vector<double> xy(2 * (size_t)n_n);
-            for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
-            CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
             c->n_count_blocks = (int)grid_for(c->n_int, kBlock);
         }
+    }
+    {   // interleaved (x, y) per node: the kernels recompute dphi / weight from the coordinates
+        std::vector<double> xy(2 * (size_t)n_n);
+        for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
+        CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
+        const char* ge = std::getenv("FEP_ELEM_GEO");
+        // measured on MI355X (1 M elements): Q1 0.204 vs 0.218 ms with recomputed geometry; P2 0.471 vs 0.430 ms and
+        // Q2 0.394 vs 0.391 ms (the coordinate staging costs LDS, hence a resident workgroup)
+        c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : elem_type == FEP_Q1;
     }
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
@@ -761,9 +765,12 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
                           double* Kc, double* fe) {
     constexpr int EB = ElemCfg<NP, NQ>::EB;
     static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
-    hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U>), dim3(grid_for(c->n_e, EB)), dim3(kBlock), 0, st,
-                       c->n_e, c->elem, c->dphi1, c->dphi2, c->weight, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu,
-                       accept, eout, s, ds, indp, blk_counts, Kc, fe);
+#define ELEM_LAUNCH(GEO)                                                                                                \
+    hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO>), dim3(grid_for(c->n_e, EB)), dim3(kBlock), 0, st, c->n_e,    \
+                       c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,       \
+                       c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts, Kc, fe)
+    if (c->elem_geo) ELEM_LAUNCH(true); else ELEM_LAUNCH(false);
+#undef ELEM_LAUNCH
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }

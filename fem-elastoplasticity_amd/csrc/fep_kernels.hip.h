@@ -245,6 +245,30 @@ geometry_kernel(int64_t n_e, int64_t n_n, const int32_t* __restrict__ elem, cons
 //
 //  FROM_U = true : inputs U (+ ep, materials);  FROM_U = false : inputs DS, S (assembly only).
 // ---------------------------------------------------------------------------------------
+// dphi and weight of one integration point from the element's node coordinates: same operations, same order,
+// no FMA contraction as geometry_kernel, hence bit-identical to the stored arrays (DP:530-546, 585).
+template <int NP>
+__device__ __forceinline__ void geometry_at_q(const double* __restrict__ t1, const double* __restrict__ t2, double wfq,
+                                              int q, int nq, const double x[NP], const double y[NP],
+                                              double d1[NP], double d2[NP], double& w) {
+#pragma clang fp contract(off)
+    double j11 = 0.0, j12 = 0.0, j21 = 0.0, j22 = 0.0;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {                       // DP:530-533
+        const double h1 = t1[a * nq + q], h2 = t2[a * nq + q];
+        j11 = j11 + x[a] * h1; j12 = j12 + y[a] * h1; j21 = j21 + x[a] * h2; j22 = j22 + y[a] * h2;
+    }
+    const double det = j11 * j22 - j12 * j21;
+    const double i11 = j22 / det, i12 = -j12 / det, i21 = -j21 / det, i22 = j11 / det;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+        const double h1 = t1[a * nq + q], h2 = t2[a * nq + q];
+        d1[a] = i11 * h1 + i12 * h2;                     // DP:545-546
+        d2[a] = i21 * h1 + i22 * h2;
+    }
+    w = fabs(det) * wfq;                                 // DP:585
+}
+
 // Homogeneous material (the reference's demos: one constant per parameter, DP:972-984): the four per-point
 // arrays are not read at all.  `on` is set by fep_ctx_set_materials_host when every array is constant.
 struct MatU { double shear, bulk, eta, c; int on; };
@@ -265,10 +289,13 @@ template <int NP, int NQ> struct ElemCfg {
     static constexpr int NPTS = EB * NQS;
 };
 
-template <int NP, int NQ, bool FROM_U>
+template <int NP, int NQ, bool FROM_U, bool GEO>
 __global__ void __launch_bounds__(kBlock)
 element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                const double* __restrict__ dphi1, const double* __restrict__ dphi2, const double* __restrict__ weight,
+               // GEO: geometry recomputed from the coordinates (xy interleaved) and the reference-element tables
+               const double* __restrict__ xy, const double* __restrict__ dh1, const double* __restrict__ dh2,
+               const double* __restrict__ wf,
                // FROM_U inputs
                const double* __restrict__ U, E0 e0, double* __restrict__ ep,
                const double* __restrict__ shear, const double* __restrict__ bulk,
@@ -283,17 +310,24 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     constexpr int NJ = NP / 2 + 1;                   // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
     __shared__ double d1s[NP][NPTS], d2s[NP][NPTS];
     __shared__ double Ds[6][NPTS], Ss[3][NPTS];
-    __shared__ int32_t nds[NP][EB];
+    __shared__ double2 cxy[GEO ? NP : 1][EB], cu[FROM_U ? NP : 1][EB];   // node coordinates / displacements per element
+    __shared__ double t1[GEO ? NP * NQ : 1], t2[GEO ? NP * NQ : 1], tw[GEO ? NQ : 1];
 
     const int t = threadIdx.x;
     const int64_t e0blk = (int64_t)blockIdx.x * EB;
     const int64_t n_int = n_e * NQ;
     const int nel = (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
 
-    if (FROM_U) {
+    if (FROM_U || GEO) {
         for (int i = t; i < NP * EB; i += kBlock) {
             const int a = i / EB, el = i - a * EB;
-            nds[a][el] = el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0;
+            const int64_t nd = el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0;
+            if (GEO) cxy[a][el] = *reinterpret_cast<const double2*>(xy + 2 * nd);
+            if (FROM_U) cu[a][el] = *reinterpret_cast<const double2*>(U + 2 * nd);
+        }
+        if (GEO) {
+            for (int i = t; i < NP * NQ; i += kBlock) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+            for (int i = t; i < NQ; i += kBlock) tw[i] = wf[i];
         }
         __syncthreads();
     }
@@ -305,17 +339,27 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         if (el >= nel) continue;
         const int64_t k = e0blk * NQ + pt;
         const int li = el * NQS + q;
-        const double w = weight[k];
+        double w;
+        double g1[NP], g2[NP];
+        if (GEO) {
+            double x[NP], y[NP];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { const double2 c = cxy[a][el]; x[a] = c.x; y[a] = c.y; }
+            geometry_at_q<NP>(t1, t2, tw[q], q, NQ, x, y, g1, g2, w);
+        } else {
+            w = weight[k];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { g1[a] = dphi1[(int64_t)a * n_int + k]; g2[a] = dphi2[(int64_t)a * n_int + k]; }
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { d1s[a][li] = g1[a]; d2s[a][li] = g2[a]; }
         double s[4], d[6];
         if (FROM_U) {
             double ev[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int a = 0; a < NP; ++a) {
-                const double g1 = dphi1[(int64_t)a * n_int + k], g2 = dphi2[(int64_t)a * n_int + k];
-                d1s[a][li] = g1; d2s[a][li] = g2;
-                const int32_t nd = nds[a][el];
-                const double ux = U[2 * (int64_t)nd], uy = U[2 * (int64_t)nd + 1];
-                ev[0] += g1 * ux; ev[1] += g2 * uy; ev[2] += g2 * ux + g1 * uy;   // DP:1043
+                const double2 u = cu[a][el];
+                ev[0] += g1[a] * u.x; ev[1] += g2[a] * u.y; ev[2] += g2[a] * u.x + g1[a] * u.y;   // DP:1043
             }
             double p[4] = {0.0, 0.0, 0.0, 0.0};
             if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
@@ -328,11 +372,6 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                 ep[k] = p[0]; ep[n_int + k] = p[1]; ep[2 * n_int + k] = p[2]; ep[3 * n_int + k] = p[3];
             }
         } else {
-#pragma unroll
-            for (int a = 0; a < NP; ++a) {
-                d1s[a][li] = dphi1[(int64_t)a * n_int + k];
-                d2s[a][li] = dphi2[(int64_t)a * n_int + k];
-            }
             if (DS) {
                 d[0] = DS[k]; d[1] = DS[n_int + k]; d[2] = DS[2 * n_int + k];
                 d[3] = DS[4 * n_int + k]; d[4] = DS[5 * n_int + k]; d[5] = DS[8 * n_int + k];
@@ -355,6 +394,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { kk[j][0] = 0.0; kk[j][1] = 0.0; kk[j][2] = 0.0; kk[j][3] = 0.0; }
         double f0 = 0.0, f1 = 0.0;
+#pragma unroll 1
         for (int q = 0; q < NQ; ++q) {
             const int li = el * NQS + q;
             const double D00 = Ds[0][li], D01 = Ds[1][li], D02 = Ds[2][li];
@@ -412,8 +452,18 @@ csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t
         const int32_t beg = segptr[sb], end = segptr[sb + 1];
         const uint32_t m = meta[sb];
         double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-        for (int32_t t = beg; t < end; ++t) {
-            const int32_t pv = perm[t];                         // (stored block index) * 2 + transposed
+        int32_t t = beg;
+        for (; t + 1 < end; t += 2) {                           // two gathers in flight; summation order unchanged
+            const int32_t pv = perm[t], pw = perm[t + 1];       // (stored block index) * 2 + transposed
+            const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(pv >> 1) * 4);
+            const double2* srd = reinterpret_cast<const double2*>(Kc + (int64_t)(pw >> 1) * 4);
+            const double2 r0 = src[0], r1 = src[1], q0 = srd[0], q1 = srd[1];
+            const bool tr = pv & 1, tq = pw & 1;
+            a00 += r0.x; a01 += tr ? r1.x : r0.y; a10 += tr ? r0.y : r1.x; a11 += r1.y;
+            a00 += q0.x; a01 += tq ? q1.x : q0.y; a10 += tq ? q0.y : q1.x; a11 += q1.y;
+        }
+        if (t < end) {
+            const int32_t pv = perm[t];
             const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(pv >> 1) * 4);
             const double2 r0 = src[0], r1 = src[1];
             const bool tr = pv & 1;
@@ -815,28 +865,6 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
 //                            sum_q w B_a^T DS B_b over its block's contributions in fixed order.
 //   gather code = local element << 8 | a << 4 | b  (uint16; <= 256 elements per tile, n_p <= 16)
 // ---------------------------------------------------------------------------------------
-template <int NP>
-__device__ __forceinline__ void geometry_at_q(const double* __restrict__ t1, const double* __restrict__ t2, double wfq,
-                                              int q, int nq, const double x[NP], const double y[NP],
-                                              double d1[NP], double d2[NP], double& w) {
-#pragma clang fp contract(off)
-    double j11 = 0.0, j12 = 0.0, j21 = 0.0, j22 = 0.0;
-#pragma unroll
-    for (int a = 0; a < NP; ++a) {                       // DP:530-533
-        const double h1 = t1[a * nq + q], h2 = t2[a * nq + q];
-        j11 = j11 + x[a] * h1; j12 = j12 + y[a] * h1; j21 = j21 + x[a] * h2; j22 = j22 + y[a] * h2;
-    }
-    const double det = j11 * j22 - j12 * j21;
-    const double i11 = j22 / det, i12 = -j12 / det, i21 = -j21 / det, i22 = j11 / det;
-#pragma unroll
-    for (int a = 0; a < NP; ++a) {
-        const double h1 = t1[a * nq + q], h2 = t2[a * nq + q];
-        d1[a] = i11 * h1 + i12 * h2;                     // DP:545-546
-        d2[a] = i21 * h1 + i22 * h2;
-    }
-    w = fabs(det) * wfq;                                 // DP:585
-}
-
 template <int NP, int NQ>
 __global__ void __launch_bounds__(kBlock)
 point_kernel(int64_t n_e, const int32_t* __restrict__ elem, const double* __restrict__ xy,
