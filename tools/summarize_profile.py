@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output directories (gpurun_out/...) into the small tracked files under profiles/.
 
-    python tools/summarize_profile.py <round-tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir>
+    python tools/summarize_profile.py <round-tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> [elements per GPU of the profiled run]
 
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3's --stats table, fep kernels + totals),
 profiles/<tag>_hbm_traffic.csv (per kernel FETCH_SIZE / WRITE_SIZE averages and corrected bytes) and
@@ -64,7 +64,8 @@ def main():
     dom = [k for k in traffic if any(s in k for s in ('p1_point_kernel', 'p1_node', 'p1_fused', 'element_kernel'))]
     json.dump({'round': tag, 'kernels': {k: traffic[k] for k in dom},
                'hbm_bytes_per_launch': sum(traffic[k] for k in dom),
-               'note': 'sum over the return-map + assembly kernels of one step; 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes'},
+               'note': 'sum over the return-map + assembly kernels of one step; 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes',
+               'elements_per_gpu': int(sys.argv[5]) if len(sys.argv) > 5 else 1002528},
               open(os.path.join(out, 'traffic_latest.json'), 'w'), indent=1)
     for r in rows[:6]:
         print(short(r['Name'])[:60], r['Calls'], r['AverageNs'], r['Percentage'])
