@@ -11,6 +11,7 @@
 // masked out (rows and columns), the solution is 0 there.  M = the 2x2 node blocks of K[Q][:,Q].
 #include "fep_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -211,6 +212,186 @@ pcg_scalar_kernel(Scal* sc, const double* part_g, const double* part_r, int n_ve
     *sc = s;
 }
 
+
+// ---- multigrid preconditioner (smoothed aggregation; hierarchy built on the host, fep_solver_amg_push_level) ----
+// Level 0 works on the block matrix K itself: out = Q (b - K x)  or, SMOOTH, one damped block-Jacobi sweep
+// out = x + omega M^-1 Q (b - K x)   (x != out).
+template <bool SMOOTH>
+__global__ void __launch_bounds__(TPB)
+block_residual_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol,
+                      const uint8_t* __restrict__ free_dof, const double2* __restrict__ K2,
+                      const double2* __restrict__ x, const double* __restrict__ b, const double* __restrict__ minv,
+                      double omega, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 7, grp = lane >> 3, comp = grp & 1;
+    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + (grp >> 1);
+    double acc[SPMV_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+        const int64_t n = node0 + ps * NODES_PER_WAVE;
+        acc[ps] = 0.0;
+        if (n < n_n) {
+            const int b0 = nptr[n], deg = nptr[n + 1] - b0;
+            const double2* row = K2 + 2 * (int64_t)b0 + (int64_t)comp * deg;
+            for (int t = sub; t < deg; t += 8) {
+                const double2 k = row[t];
+                const double2 xv = x[ncol[b0 + t]];
+                acc[ps] += k.x * xv.x + k.y * xv.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+        double a = acc[ps];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        const int64_t n = node0 + ps * NODES_PER_WAVE;
+        const bool live = n < n_n;
+        const int64_t dof = 2 * n + comp;
+        double r = 0.0;
+        if (live && sub == 0 && free_dof[dof]) r = b[dof] - a;
+        if (SMOOTH) {
+            const double other = __shfl_xor(r, 8, 64);              // the node's other component
+            if (live && sub == 0) {
+                const double r0 = comp == 0 ? r : other, r1 = comp == 0 ? other : r;
+                const double m0 = minv[3 * n], m1 = minv[3 * n + 1], m2 = minv[3 * n + 2];
+                const double d = comp == 0 ? m0 * r0 + m1 * r1 : m1 * r0 + m2 * r1;
+                const double xo = comp == 0 ? x[n].x : x[n].y;
+                out[dof] = free_dof[dof] ? xo + omega * d : 0.0;
+            }
+        } else if (live && sub == 0) {
+            out[dof] = r;
+        }
+    }
+}
+
+// x = omega M^-1 Q b  (first sweep from x = 0)
+__global__ void __launch_bounds__(TPB)
+block_scale_kernel(int64_t n_n, const uint8_t* __restrict__ free_dof, const double* __restrict__ minv,
+                   const double2* __restrict__ b, double omega, double2* __restrict__ x) {
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (n >= n_n) return;
+    double2 r = b[n];
+    if (!free_dof[2 * n]) r.x = 0.0;
+    if (!free_dof[2 * n + 1]) r.y = 0.0;
+    const double m0 = minv[3 * n], m1 = minv[3 * n + 1], m2 = minv[3 * n + 2];
+    x[n] = make_double2(omega * (m0 * r.x + m1 * r.y), omega * (m1 * r.x + m2 * r.y));
+}
+
+// Coarse levels and transfers: scalar CSR, 8 lanes per row:  y = c0 * z + c1 * A x   (z == nullptr: y = c1 * A x;
+// y may alias z, never x)
+__global__ void __launch_bounds__(TPB)
+csr_kernel(int64_t n_rows, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+           const double* __restrict__ vals, const double* __restrict__ x, const double* z, double c0, double c1,
+           double* y) {
+    const int sub = threadIdx.x & 7;
+    const int64_t row = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 3;
+    double a = 0.0;
+    if (row < n_rows) {
+        const int32_t e = indptr[row + 1];
+        for (int32_t t = indptr[row] + sub; t < e; t += 8) a += vals[t] * x[indices[t]];
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (row < n_rows && sub == 0) y[row] = (z ? c0 * z[row] : 0.0) + c1 * a;
+}
+
+// standard PCG pieces around the V-cycle
+__global__ void __launch_bounds__(TPB)
+mg_init_kernel(int64_t n_n, const double2* __restrict__ b, const uint8_t* __restrict__ free_dof, double2* __restrict__ x,
+               double2* __restrict__ r, double* __restrict__ part_r) {
+    __shared__ double sh[TPB / 64];
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    double rr = 0.0;
+    if (n < n_n) {
+        double2 rv = b[n];
+        if (!free_dof[2 * n]) rv.x = 0.0;
+        if (!free_dof[2 * n + 1]) rv.y = 0.0;
+        x[n] = make_double2(0.0, 0.0); r[n] = rv;
+        rr = rv.x * rv.x + rv.y * rv.y;
+    }
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) part_r[blockIdx.x] = rr;
+}
+
+// partial sums of (a, b); COPY: p = a as well (first iteration: p = z)
+template <bool COPY>
+__global__ void __launch_bounds__(TPB)
+mg_dot_kernel(int64_t n_n, const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ p,
+              double* __restrict__ part) {
+    __shared__ double sh[TPB / 64];
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    double d = 0.0;
+    if (n < n_n) {
+        const double2 av = a[n], bv = b[n];
+        d = av.x * bv.x + av.y * bv.y;
+        if (COPY) p[n] = av;
+    }
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = d;
+}
+
+// x += alpha p, r -= alpha q; partial sums of (r, r)
+__global__ void __launch_bounds__(TPB)
+mg_update_kernel(int64_t n_n, const Scal* __restrict__ sc, const double2* __restrict__ p, const double2* __restrict__ q,
+                 double2* __restrict__ x, double2* __restrict__ r, double* __restrict__ part_r) {
+    __shared__ double sh[TPB / 64];
+    const double alpha = sc->alpha;
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    double rr = 0.0;
+    if (n < n_n) {
+        double2 rv = r[n];
+        if (alpha != 0.0) {
+            const double2 pv = p[n], qv = q[n];
+            double2 xv = x[n];
+            xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+            rv.x -= alpha * qv.x; rv.y -= alpha * qv.y;
+            x[n] = xv; r[n] = rv;
+        }
+        rr = rv.x * rv.x + rv.y * rv.y;
+    }
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) part_r[blockIdx.x] = rr;
+}
+
+// p = z + beta p
+__global__ void __launch_bounds__(TPB)
+mg_direction_kernel(int64_t n_n, const Scal* __restrict__ sc, const double2* __restrict__ z, double2* __restrict__ p) {
+    const double beta = sc->beta;
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (n >= n_n || sc->state != 0) return;
+    const double2 zv = z[n];
+    double2 pv = p[n];
+    pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
+    p[n] = pv;
+}
+
+// scalar steps of the standard PCG: which = 0 after the first (r, z): gamma, bb; 1 after (p, q): alpha;
+// 2 after the update and the new (r, z): stopping test, beta
+__global__ void __launch_bounds__(1024)
+mg_scalar_kernel(Scal* sc, int which, const double* part_a, int n_a, const double* part_b, int n_b, double tol2) {
+    __shared__ double sh[16];
+    const double a = sum_partials(part_a, n_a, sh);
+    const double b = part_b ? sum_partials(part_b, n_b, sh) : 0.0;
+    if (threadIdx.x != 0) return;
+    Scal s = *sc;
+    if (which == 0) {                       // a = (r, z), b = (r, r)
+        s.bb = b; s.rr = b; s.gamma = a; s.it = 0; s.alpha = 0.0; s.beta = 0.0;
+        s.state = b == 0.0 ? 1 : (!(a > 0.0) ? 2 : 0);
+    } else if (s.state == 0 && which == 1) { // a = (p, q)
+        if (!(a > 0.0)) { s.state = 2; s.alpha = 0.0; } else s.alpha = s.gamma / a;
+    } else if (s.state == 0) {              // a = (r, z) new, b = (r, r) new
+        s.it += 1; s.rr = b;
+        if (b <= tol2 * s.bb) { s.state = 1; s.alpha = 0.0; s.beta = 0.0; }
+        else if (!(a > 0.0) || !(a == a)) { s.state = 2; s.alpha = 0.0; s.beta = 0.0; }
+        else { s.beta = a / s.gamma; s.gamma = a; }
+    }
+    if (s.state != 0) { s.alpha = 0.0; s.beta = 0.0; }
+    *sc = s;
+}
+
 }  // namespace
 
 struct fep_solver {
@@ -222,7 +403,32 @@ struct fep_solver {
     double *part_g = nullptr, *part_r = nullptr, *part_d = nullptr;
     Scal* scal = nullptr;
     int n_vec_blocks = 0, n_mv_blocks = 0;
+    // multigrid preconditioner: level k (k = 0 is the mesh) -> level k+1
+    struct Csr { int64_t n_rows = 0, nnz = 0; int32_t *indptr = nullptr, *indices = nullptr; double* vals = nullptr; };
+    struct Level {
+        int64_t n_fine = 0, n_coarse = 0;
+        Csr P, R, A, D;                       // A, D: operator of level k+1 (A = its inverse when last) and its block-Jacobi inverse
+        double omega = 0.0;                   // damping of the smoother on level k
+        bool last = false;
+        double *x = nullptr, *b = nullptr, *r = nullptr;      // vectors of level k+1
+    };
+    std::vector<Level> levels;
+    double *t0 = nullptr, *q = nullptr;       // level-0 residual of the V-cycle, q = K p
 };
+
+static void free_csr(fep_solver::Csr& m) {
+    if (m.indptr) (void)hipFree(m.indptr);
+    if (m.indices) (void)hipFree(m.indices);
+    if (m.vals) (void)hipFree(m.vals);
+    m = fep_solver::Csr();
+}
+static void free_levels(fep_solver* s) {
+    for (auto& l : s->levels) {
+        free_csr(l.P); free_csr(l.R); free_csr(l.A); free_csr(l.D);
+        for (double* v : {l.x, l.b, l.r}) if (v) (void)hipFree(v);
+    }
+    s->levels.clear();
+}
 
 extern "C" int fep_solver_destroy(fep_solver* s) {
     if (!s) return FEP_OK;
@@ -231,6 +437,9 @@ extern "C" int fep_solver_destroy(fep_solver* s) {
                         s->part_g, s->part_r, s->part_d, s->scal};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
+        if (s->t0) (void)hipFree(s->t0);
+        if (s->q) (void)hipFree(s->q);
+        free_levels(s);
     }
     delete s;
     return FEP_OK;
@@ -355,5 +564,204 @@ extern "C" int fep_solver_pcg_dev(fep_solver* s, void* stream, const double* k_d
     if (iters_out) *iters_out = h.it;
     if (relres_out) *relres_out = h.bb > 0.0 ? std::sqrt(h.rr / h.bb) : 0.0;
     if (state_out) *state_out = h.state;
+    return FEP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Multigrid-preconditioned conjugate gradients
+// ---------------------------------------------------------------------------------------
+extern "C" int fep_solver_amg_clear(fep_solver* s) {
+    if (!s) return FEP_EINVAL;
+    FEP_TRY(fep_set_device(s->device));
+    free_levels(s);
+    return FEP_OK;
+}
+
+static int upload_csr(fep_solver::Csr& m, int64_t n_rows, int64_t n_cols, const int32_t* ip, const int32_t* ix,
+                      const double* v) {
+    if (!ip || !ix || !v || ip[0] != 0) return FEP_EINVAL;
+    const int64_t nnz = ip[n_rows];
+    for (int64_t i = 0; i < n_rows; ++i)
+        if (ip[i + 1] < ip[i]) return FEP_EINVAL;
+    for (int64_t t = 0; t < nnz; ++t)
+        if (ix[t] < 0 || ix[t] >= n_cols) return FEP_ERANGE;
+    m.n_rows = n_rows; m.nnz = nnz;
+    HIP_TRY(hipMalloc((void**)&m.indptr, (size_t)(n_rows + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&m.indices, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&m.vals, (size_t)std::max<int64_t>(nnz, 1) * sizeof(double)));
+    HIP_TRY(hipMemcpy(m.indptr, ip, (size_t)(n_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m.indices, ix, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m.vals, v, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    return FEP_OK;
+}
+
+extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t n_coarse,
+                                         const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
+                                         const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,
+                                         const int32_t* a_indptr, const int32_t* a_indices, const double* a_vals,
+                                         const int32_t* d_indptr, const int32_t* d_indices, const double* d_vals,
+                                         double omega_fine, int last) {
+    if (!s || n_fine <= 0 || n_coarse <= 0 || !(omega_fine > 0.0)) return FEP_EINVAL;
+    if (!s->levels.empty() && (s->levels.back().last || s->levels.back().n_coarse != n_fine)) return FEP_ESTATE;
+    if (s->levels.empty() && n_fine != s->n_dof) return FEP_EINVAL;
+    if (!last && !d_indptr) return FEP_EINVAL;
+    FEP_TRY(fep_set_device(s->device));
+    s->levels.emplace_back();
+    fep_solver::Level& l = s->levels.back();
+    l.n_fine = n_fine; l.n_coarse = n_coarse; l.omega = omega_fine; l.last = last != 0;
+    int rc = upload_csr(l.P, n_fine, n_coarse, p_indptr, p_indices, p_vals);
+    if (rc == FEP_OK) rc = upload_csr(l.R, n_coarse, n_fine, r_indptr, r_indices, r_vals);
+    if (rc == FEP_OK) rc = upload_csr(l.A, n_coarse, n_coarse, a_indptr, a_indices, a_vals);
+    if (rc == FEP_OK && !last) rc = upload_csr(l.D, n_coarse, n_coarse, d_indptr, d_indices, d_vals);
+    for (double** v : {&l.x, &l.b, &l.r})
+        if (rc == FEP_OK && hipMalloc((void**)v, (size_t)n_coarse * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = FEP_ENOMEM;
+        }
+    if (rc == FEP_OK && !s->t0) {
+        if (hipMalloc((void**)&s->t0, (size_t)s->n_dof * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&s->q, (size_t)s->n_dof * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
+    }
+    if (rc != FEP_OK) {
+        fep_solver::Level& b = s->levels.back();
+        free_csr(b.P); free_csr(b.R); free_csr(b.A); free_csr(b.D);
+        for (double* v : {b.x, b.b, b.r}) if (v) (void)hipFree(v);
+        s->levels.pop_back();
+    }
+    return rc;
+}
+
+namespace {
+
+inline void csr_apply(hipStream_t st, const fep_solver::Csr& m, const double* x, const double* z, double c0, double c1,
+                      double* y) {
+    const unsigned grid = (unsigned)((m.n_rows * 8 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(csr_kernel, dim3(grid), dim3(TPB), 0, st, m.n_rows, m.indptr, m.indices, m.vals, x, z, c0, c1, y);
+}
+
+// z = V-cycle(b) on K; returns the buffer that holds z (one of s->u, s->w).  Two damped block-Jacobi sweeps before
+// and after the coarse correction on every level, hence a symmetric positive definite operator.
+double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0) {
+    const dim3 gv(s->n_vec_blocks), gm(s->n_mv_blocks), tb(TPB);
+    const double2* K2 = (const double2*)K;
+    std::vector<fep_solver::Level>& L = s->levels;
+    const int nl = (int)L.size();
+    double *xa = s->u, *xb = s->w;
+    const double w0 = L[0].omega;
+    // level 0, pre-smoothing from x = 0
+    hipLaunchKernelGGL(block_scale_kernel, gv, tb, 0, st, s->n_n, s->free_dof, s->minv, (const double2*)b0, w0, (double2*)xa);
+    hipLaunchKernelGGL(block_residual_kernel<true>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
+                       (const double2*)xa, b0, s->minv, w0, xb);
+    hipLaunchKernelGGL(block_residual_kernel<false>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
+                       (const double2*)xb, b0, s->minv, 0.0, s->t0);
+    csr_apply(st, L[0].R, s->t0, nullptr, 0.0, 1.0, L[0].b);
+    // coarse levels down: level k+1 lives in L[k].{A, D, x, b, r}; its smoother weight is L[k+1].omega
+    for (int k = 0; k + 1 < nl; ++k) {
+        fep_solver::Level& c = L[k];
+        const double w = L[k + 1].omega;
+        csr_apply(st, c.D, c.b, nullptr, 0.0, w, c.x);               // x = w D b
+        csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);                // r = b - A x
+        csr_apply(st, c.D, c.r, c.x, 1.0, w, c.x);                   // x += w D r
+        csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
+        csr_apply(st, L[k + 1].R, c.r, nullptr, 0.0, 1.0, L[k + 1].b);
+    }
+    // coarsest: x = A^-1 b (A holds the inverse)
+    csr_apply(st, L[nl - 1].A, L[nl - 1].b, nullptr, 0.0, 1.0, L[nl - 1].x);
+    // up
+    for (int k = nl - 2; k >= 0; --k) {
+        fep_solver::Level& c = L[k];
+        const double w = L[k + 1].omega;
+        csr_apply(st, L[k + 1].P, L[k + 1].x, c.x, 1.0, 1.0, c.x);   // x += P x_coarse
+        for (int sw = 0; sw < 2; ++sw) {
+            csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
+            csr_apply(st, c.D, c.r, c.x, 1.0, w, c.x);
+        }
+    }
+    csr_apply(st, L[0].P, L[0].x, xb, 1.0, 1.0, xb);
+    hipLaunchKernelGGL(block_residual_kernel<true>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
+                       (const double2*)xb, b0, s->minv, w0, xa);
+    hipLaunchKernelGGL(block_residual_kernel<true>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
+                       (const double2*)xa, b0, s->minv, w0, xb);
+    return xb;
+}
+
+}  // namespace
+
+extern "C" int fep_solver_amg_pcg_dev(fep_solver* s, void* stream, const double* k_data_d, const double* b_d, double* x_d,
+                                      double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
+                                      int* state_out) {
+    if (!s || !k_data_d || !b_d || !x_d || !(rtol >= 0.0) || max_iter < 0) return FEP_EINVAL;
+    if (s->levels.empty() || !s->levels.back().last) return FEP_ESTATE;
+    if (check_every <= 0) check_every = 10;
+    FEP_TRY(fep_set_device(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gv(s->n_vec_blocks), gm(s->n_mv_blocks), tb(TPB), one(1), big(1024);
+    const double tol2 = rtol * rtol;
+    double2 *x = (double2*)x_d, *r = (double2*)s->r, *p = (double2*)s->p;
+    hipLaunchKernelGGL(block_jacobi_kernel, gv, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, k_data_d, s->minv);
+    hipLaunchKernelGGL(mg_init_kernel, gv, tb, 0, st, s->n_n, (const double2*)b_d, s->free_dof, x, r, s->part_r);
+    double* z = vcycle(s, st, k_data_d, s->r);
+    hipLaunchKernelGGL(mg_dot_kernel<true>, gv, tb, 0, st, s->n_n, (const double2*)z, (const double2*)r, p, s->part_g);
+    hipLaunchKernelGGL(mg_scalar_kernel, one, big, 0, st, s->scal, 0, s->part_g, s->n_vec_blocks, s->part_r,
+                       s->n_vec_blocks, tol2);
+    HIP_TRY(hipGetLastError());
+    Scal h;
+    std::memset(&h, 0, sizeof h);
+    int launched = 0;
+    for (;;) {
+        HIP_TRY(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h.state != 0 || launched >= max_iter) break;
+        const int n = std::min(check_every, max_iter - launched);
+        for (int i = 0; i < n; ++i) {
+            hipLaunchKernelGGL(spmv_kernel<true>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof,
+                               (const double2*)k_data_d, (const double2*)p, s->q, (const double*)s->p, s->part_d);
+            hipLaunchKernelGGL(mg_scalar_kernel, one, big, 0, st, s->scal, 1, s->part_d, s->n_mv_blocks,
+                               (const double*)nullptr, 0, tol2);
+            hipLaunchKernelGGL(mg_update_kernel, gv, tb, 0, st, s->n_n, s->scal, (const double2*)p, (const double2*)s->q,
+                               x, r, s->part_r);
+            z = vcycle(s, st, k_data_d, s->r);
+            hipLaunchKernelGGL(mg_dot_kernel<false>, gv, tb, 0, st, s->n_n, (const double2*)z, (const double2*)r,
+                               (double2*)nullptr, s->part_g);
+            hipLaunchKernelGGL(mg_scalar_kernel, one, big, 0, st, s->scal, 2, s->part_g, s->n_vec_blocks, s->part_r,
+                               s->n_vec_blocks, tol2);
+            hipLaunchKernelGGL(mg_direction_kernel, gv, tb, 0, st, s->n_n, s->scal, (const double2*)z, p);
+        }
+        HIP_TRY(hipGetLastError());
+        launched += n;
+    }
+    if (iters_out) *iters_out = h.it;
+    if (relres_out) *relres_out = h.bb > 0.0 ? std::sqrt(h.rr / h.bb) : 0.0;
+    if (state_out) *state_out = h.state;
+    return FEP_OK;
+}
+
+// Greedy aggregation of a node graph (CSR, self loops allowed): pass 1 makes an aggregate of every node whose
+// neighbours are all free, pass 2 attaches the rest to a neighbouring aggregate (or makes singletons).
+extern "C" int fep_aggregate_host(int64_t n, const int32_t* indptr, const int32_t* indices, int32_t* agg_out,
+                                  int64_t* n_agg_out) {
+    if (n <= 0 || !indptr || !indices || !agg_out || !n_agg_out) return FEP_EINVAL;
+    std::vector<int32_t> agg((size_t)n, -1);
+    int32_t na = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        bool free_nb = true;
+        for (int32_t t = indptr[i]; t < indptr[i + 1] && free_nb; ++t) {
+            if (indices[t] < 0 || indices[t] >= n) return FEP_ERANGE;
+            free_nb = agg[indices[t]] < 0;
+        }
+        if (!free_nb) continue;
+        for (int32_t t = indptr[i]; t < indptr[i + 1]; ++t) agg[indices[t]] = na;
+        agg[i] = na++;
+    }
+    std::vector<int32_t> fin(agg);
+    for (int64_t i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        int32_t a = -1;
+        for (int32_t t = indptr[i]; t < indptr[i + 1] && a < 0; ++t) a = agg[indices[t]];
+        fin[i] = a >= 0 ? a : na++;
+    }
+    std::memcpy(agg_out, fin.data(), (size_t)n * sizeof(int32_t));
+    *n_agg_out = na;
     return FEP_OK;
 }

@@ -10,8 +10,9 @@ Per Newton iterate ONE call of the fused step replaces DP:1043-1058 (strain, ret
 Step control, stopping norms and the extrapolation of the next iterate follow the reference line by line.
 The linear solve (the reference's dense `np.linalg.solve` on a (2 n_n)^2 boolean-masked matrix) is
   linear_solver='direct'  SciPy SuperLU on the host CSR matrix (K travels to the host every iterate), or
-  linear_solver='pcg'     conjugate gradients on the GPU (solver.py); the iterate, K, F, the plastic strain and
-                          the stopping norms then never leave the device.
+  linear_solver='pcg'     conjugate gradients on the GPU (solver.py, block-Jacobi preconditioner); the iterate, K, F,
+                          the plastic strain and the stopping norms then never leave the device, or
+  linear_solver='amg'     the same with the smoothed-aggregation multigrid preconditioner built once from K_elast.
 `transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is re-stated
 with `np.bincount` on the host and as `fep_transform_dev` on the device.
 """
@@ -125,6 +126,11 @@ class _DeviceOps:
             out['n_smooth'], out['n_apex'] = int(c[0]), int(c[1])
         return out
 
+    def setup_amg(self, K, coordinates):
+        # built once from K_elast; rebuilding it from the current tangent when the plastic zone grows was measured
+        # (1 M elements, 10 load steps: 6 rebuilds) and did not lower the iteration counts
+        self.solver.setup_amg(self.host(K), coordinates)
+
     def solve(self, K, rhs):
         x = self.solver.pcg(K, rhs, rtol=self.rtol, max_iter=self.max_iter)
         self.pcg_iters.append(self.solver.last['iters'])
@@ -156,11 +162,11 @@ class _DeviceOps:
 def _make_ops(ctx, qf, linear_solver, pcg_rtol):
     if linear_solver == 'direct':
         return _HostOps(ctx, qf)
-    if linear_solver == 'pcg':
+    if linear_solver in ('pcg', 'amg'):
         if not isinstance(ctx, MeshContext):
-            raise ValueError("linear_solver='pcg' needs the GPU MeshContext")
+            raise ValueError(f"linear_solver='{linear_solver}' needs the GPU MeshContext")
         return _DeviceOps(ctx, qf, rtol=pcg_rtol)
-    raise ValueError("linear_solver must be 'direct' or 'pcg'")
+    raise ValueError("linear_solver must be 'direct', 'pcg' or 'amg'")
 
 
 def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, max_steps=None, zeta_max=1.0,
@@ -187,6 +193,8 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     qf = Q.flatten(order='F')
     ops = _make_ops(ctx, qf, linear_solver, pcg_rtol)
     K_elast = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                        # DP:977
+    if linear_solver == 'amg':
+        ops.setup_amg(K_elast, coord)
     _, _, weight, _ = ctx.geometry()
 
     d_zeta = 1 / 1000                                                                     # DP:989-994
@@ -284,6 +292,8 @@ def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(
     ctx.set_materials(shear0, bulk0, eta0, c_0)
     ops = _make_ops(ctx, qf, linear_solver, pcg_rtol)
     K = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                              # TSX:1722
+    if linear_solver == 'amg':
+        ops.setup_amg(K, coords)
     _, F0 = ctx.assemble(None, s0 * np.ones((1, n_int)))                                   # TSX:1737
 
     d_zeta = 1 / n_load_steps                                                             # TSX:1730-1735

@@ -4,12 +4,92 @@ Linear solve of one Newton iterate on the GPU ("later a GPU Kry
 Preconditioned conjugate gradients (2x2 node-block Jacobi) in HIP, `fep_solver_*` of include/fep.h.  K is used
 where the assembly kernels left it: the `data` array on the context's CSR pattern, in device memory.  torch
 tensors are only the holders of device memory here.
+
+Two preconditioners: the 2x2 node-block Jacobi that is always there, and a smoothed-aggregation multigrid
+(`setup_amg`): aggregates of the node graph, tentative prolongators from the rigid-body modes (two translations and
+the rotation, 3 DOFs per aggregate), one damped-Jacobi smoothing step of the prolongator, Galerkin coarse operators.
+The hierarchy is built once per mesh on the host with SciPy from a reference matrix (K_elast) and lives on the GPU;
+every solve smooths with the CURRENT tangent on the mesh level and keeps the coarse operators of the reference
+matrix (a tangent that softens in the plastic zone costs ~20 % more iterations than its own hierarchy would).
 """
 import ctypes as C
 
 import numpy as np
+import scipy.sparse as ssp
 
 from . import _lib
+
+
+def _block_diag(A, bs):
+    """(n, bs, bs) array of the diagonal blocks of the CSR matrix A."""
+    n = A.shape[0] // bs
+    D = np.zeros((n, bs, bs))
+    for b in range(bs):
+        for c in range(bs):
+            k = c - b
+            d = A.diagonal(k)
+            D[:, b, c] = d[b::bs][:n] if k >= 0 else d[c::bs][:n]
+    return D
+
+
+def _block_diag_inverse(A, bs):
+    """CSR matrix of the inverted diagonal blocks (blocks of one-node aggregates have an empty rotation row)."""
+    D = _block_diag(A, bs)
+    for b in range(bs):                                  # empty rows/columns (a rotation nobody interpolates from)
+        z = D[:, b, b] == 0.0
+        D[z, b, b] = 1.0
+    tr = np.abs(np.einsum('nii->n', D)) / bs
+    D = D + (1e-13 * tr)[:, None, None] * np.eye(bs)[None]
+    Di = np.linalg.inv(D)
+    n = D.shape[0]
+    cols = (bs * np.arange(n)[:, None, None] + np.arange(bs)[None, None, :]) + np.zeros((1, bs, 1), dtype=np.int64)
+    indptr = bs * np.arange(bs * n + 1, dtype=np.int64)
+    return ssp.csr_matrix((Di.ravel(), cols.ravel(), indptr), shape=A.shape)
+
+
+def _rho(A, Di, iters=15):
+    """Largest eigenvalue of Di A by power iteration (Di A is similar to a symmetric positive semidefinite matrix)."""
+    x = np.random.default_rng(1).normal(size=A.shape[0])
+    lam = 1.0
+    for _ in range(iters):
+        y = Di @ (A @ x)
+        ny = np.linalg.norm(y)
+        if ny == 0.0:
+            return 1.0
+        lam = ny / np.linalg.norm(x)
+        x = y / ny
+    return float(lam)
+
+
+def _aggregate(A, bs):
+    coo = A.tocoo()
+    n = A.shape[0] // bs
+    G = ssp.csr_matrix((np.ones(coo.nnz, dtype=np.int8), (coo.row // bs, coo.col // bs)), shape=(n, n))
+    ip = np.ascontiguousarray(G.indptr, dtype=np.int32)
+    ix = np.ascontiguousarray(G.indices, dtype=np.int32)
+    agg = np.empty(n, dtype=np.int32)
+    na = C.c_int64()
+    _lib.check(_lib.lib().fep_aggregate_host(n, _lib.ptr(ip), _lib.ptr(ix), _lib.ptr(agg), C.byref(na)),
+               'fep_aggregate_host')
+    return agg.astype(np.int64), int(na.value)
+
+
+def _tentative(agg, na, xy, bs):
+    """Rigid-body modes of every aggregate about its centre; fine DOFs (u, v) for bs = 2, (u, v, theta) for bs = 3."""
+    n = agg.size
+    cnt = np.bincount(agg, minlength=na)
+    cx = np.bincount(agg, weights=xy[0], minlength=na) / cnt
+    cy = np.bincount(agg, weights=xy[1], minlength=na) / cnt
+    dx, dy = xy[0] - cx[agg], xy[1] - cy[agg]
+    i = np.arange(n)
+    one = np.ones(n)
+    rows = [bs * i, bs * i, bs * i + 1, bs * i + 1]
+    cols = [3 * agg, 3 * agg + 2, 3 * agg + 1, 3 * agg + 2]
+    vals = [one, -dy, one, dx]
+    if bs == 3:
+        rows.append(bs * i + 2); cols.append(3 * agg + 2); vals.append(one)
+    P = ssp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(bs * n, 3 * na))
+    return P, np.stack([cx, cy])
 
 
 def _p(t):
@@ -46,6 +126,8 @@ class KrylovSolver:
         _lib.check(_lib.lib().fep_solver_sizes(self._h, sz), 'fep_solver_sizes')
         self.n_n, self.n_dof, self.nnz, self.n_free = [int(v) for v in sz]
         self.free_dof = fd.view(np.bool_)
+        self._pattern = (ip, ix)
+        self.amg_levels = None
         self.last = None
 
     def close(self):
@@ -68,6 +150,58 @@ class KrylovSolver:
             raise ValueError(f'expected {n} contiguous float64 values')
         return v
 
+    def setup_amg(self, K_ref, coordinates, coarse_nodes=200, max_levels=8):
+        """Builds the multigrid hierarchy from `K_ref` (csr_matrix on the pattern, or its data array; host) and the
+        node coordinates (2, n_n), and loads it onto the device.  Returns [(DOFs, nnz)] per level."""
+        if not hasattr(self, '_pattern'):
+            raise ValueError('setup_amg needs the solver to have been created from a pattern')
+        ip, ix = self._pattern
+        data = K_ref.data if hasattr(K_ref, 'indptr') else np.asarray(K_ref, dtype=np.float64)
+        K = ssp.csr_matrix((data, ix, ip), shape=(self.n_dof, self.n_dof))
+        f = self.free_dof.astype(np.float64)
+        Dq = ssp.diags(f)
+        A = (Dq @ K @ Dq + ssp.diags(1.0 - f)).tocsr()
+        xy = np.asarray(coordinates, dtype=np.float64)
+        l = _lib.lib()
+        _lib.check(l.fep_solver_amg_clear(self._h), 'fep_solver_amg_clear')
+        bs, sizes = 2, [(A.shape[0], A.nnz)]
+        Di = _block_diag_inverse(A, bs)
+        rho = _rho(A, Di)
+        for level in range(max_levels):
+            agg, na = _aggregate(A, bs)
+            Pt, cxy = _tentative(agg, na, xy, bs)
+            if bs == 2:
+                Pt = (Dq @ Pt).tocsr()
+            P = (Pt - (4.0 / (3.0 * rho)) * (Di @ (A @ Pt))).tocsr()
+            Ac = (P.T @ A @ P).tocsr()
+            Ac.sum_duplicates()
+            last = na <= coarse_nodes or level == max_levels - 1 or 3 * na > 0.7 * A.shape[0]
+            omega = 4.0 / (3.0 * 1.05 * rho)
+            R = P.T.tocsr()
+            if last:
+                dense = Ac.toarray()
+                dense += 1e-10 * np.abs(dense).max() * np.eye(dense.shape[0])
+                Aop, Dc = ssp.csr_matrix(np.linalg.inv(dense)), None
+            else:
+                Aop, Dc = Ac, _block_diag_inverse(Ac, 3)
+            mats = []
+            for M in (P, R, Aop, Dc):
+                if M is None:
+                    mats += [None, None, None]
+                else:
+                    M.sort_indices()
+                    mats += [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+                             np.ascontiguousarray(M.data, dtype=np.float64)]
+            _lib.check(l.fep_solver_amg_push_level(self._h, P.shape[0], P.shape[1], *[_lib.ptr(m) for m in mats],
+                                                   float(omega), int(last)), 'fep_solver_amg_push_level')
+            sizes.append((Ac.shape[0], Ac.nnz))
+            if last:
+                break
+            A, xy, bs, Di = Ac, cxy, 3, Dc
+            rho = _rho(A, Di)
+        self.amg_levels = sizes
+        return sizes
+
     def spmv(self, k_data, x, out=None, masked=False):
         """y = K x (masked: rows of constrained DOFs zeroed; x must be 0 there).  Device tensors in and out."""
         torch = self._torch
@@ -78,18 +212,23 @@ class KrylovSolver:
                    'fep_solver_spmv_dev')
         return y
 
-    def pcg(self, k_data, b, out=None, rtol=1e-12, max_iter=100000, check_every=50):
+    def pcg(self, k_data, b, out=None, rtol=1e-12, max_iter=100000, check_every=0, precond=None):
         """Solves K[Q][:,Q] x[Q] = b[Q]; returns the full-length device tensor x (0 on constrained DOFs).
+        `precond`: 'jacobi', 'amg' (needs `setup_amg`), default = 'amg' when a hierarchy is loaded.
         `self.last` = {'iters', 'relres', 'state'} with state 1 = converged, 0 = max_iter, 2 = breakdown."""
+        if precond is None:
+            precond = 'amg' if self.amg_levels else 'jacobi'
+        if precond not in ('jacobi', 'amg'):
+            raise ValueError("precond must be 'jacobi' or 'amg'")
+        fn = _lib.lib().fep_solver_amg_pcg_dev if precond == 'amg' else _lib.lib().fep_solver_pcg_dev
         torch = self._torch
         k = self._vec(k_data, self.nnz)
         b = self._vec(b, self.n_dof)
         x = torch.empty(self.n_dof, dtype=torch.float64, device=self._dev) if out is None else out
         it, st, rr = C.c_int(), C.c_int(), C.c_double()
-        _lib.check(_lib.lib().fep_solver_pcg_dev(self._h, _stream(torch, self._dev), _p(k), _p(b), _p(x), float(rtol),
-                                                 int(max_iter), int(check_every), C.byref(it), C.byref(rr),
-                                                 C.byref(st)), 'fep_solver_pcg_dev')
-        self.last = {'iters': it.value, 'relres': rr.value, 'state': st.value}
+        _lib.check(fn(self._h, _stream(torch, self._dev), _p(k), _p(b), _p(x), float(rtol), int(max_iter),
+                      int(check_every), C.byref(it), C.byref(rr), C.byref(st)), 'fep_solver_%spcg_dev' % ('amg_' if precond == 'amg' else ''))
+        self.last = {'iters': it.value, 'relres': rr.value, 'state': st.value, 'precond': precond}
         return x
 
     def solve_host(self, K, b, **kw):

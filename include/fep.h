@@ -204,6 +204,32 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
                        double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
                        int* state_out);
 
+/* Multigrid preconditioner for the same solve (smoothed aggregation).  The hierarchy is built on the host (solver.py:
+ * aggregates from fep_aggregate_host, rigid-body-mode prolongators, Galerkin products with SciPy) from a reference
+ * matrix on the context's pattern — normally K_elast — and pushed level by level; the solver applies it as a V(2,2)
+ * cycle with damped block-Jacobi smoothing in which level 0 is always the CURRENT tangent (k_data_d of the call) and
+ * the coarse operators stay those of the reference matrix.
+ *
+ *   fep_solver_amg_push_level   transfer level k -> k+1 (k = number of levels pushed so far; level 0 = the mesh DOFs):
+ *       P (n_fine x n_coarse) and R = P^T (n_coarse x n_fine) in CSR; A = operator of level k+1 (n_coarse^2, CSR) or,
+ *       when last != 0, its INVERSE (dense rows in CSR); D = inverse of the block diagonal of A (CSR; NULL when last);
+ *       omega_fine = damping of the smoother on level k.  Rows of P belonging to constrained DOFs must be zero.
+ *   fep_solver_amg_clear        drops the hierarchy
+ *   fep_solver_amg_pcg_dev      as fep_solver_pcg_dev, preconditioned with the V-cycle (FEP_ESTATE without a complete
+ *                               hierarchy); check_every <= 0: 10
+ *   fep_aggregate_host          greedy aggregation of a node graph in CSR: agg_out[i] in [0, *n_agg_out) */
+int fep_solver_amg_clear(fep_solver* solver);
+int fep_solver_amg_push_level(fep_solver* solver, int64_t n_fine, int64_t n_coarse,
+                              const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
+                              const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,
+                              const int32_t* a_indptr, const int32_t* a_indices, const double* a_vals,
+                              const int32_t* d_indptr, const int32_t* d_indices, const double* d_vals,
+                              double omega_fine, int last);
+int fep_solver_amg_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d, const double* b_d, double* x_d,
+                           double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
+                           int* state_out);
+int fep_aggregate_host(int64_t n, const int32_t* indptr, const int32_t* indices, int32_t* agg_out, int64_t* n_agg_out);
+
 /* ---- in-situ kernel timing (bench.py's roofline figure) --------------------------------
  * Between fep_ctx_profile_begin and fep_ctx_profile_end every fep_step_dev / fep_assemble_dev call
  * brackets each of its kernels with HIP events on the launch stream (the kernels run in their real

@@ -74,7 +74,7 @@ def test_pcg_edge_cases(fep):
     # zero right-hand side on the free DOFs: x = 0 without iterating
     b0 = np.where(qf, 0.0, 7.0)
     x = sol.solve_host(K, b0)
-    assert sol.last == {'iters': 0, 'relres': 0.0, 'state': 1} and np.all(x == 0.0)
+    assert (sol.last['iters'], sol.last['relres'], sol.last['state']) == (0, 0.0, 1) and np.all(x == 0.0)
     # a negative definite matrix is reported as breakdown, not iterated on
     x = sol.solve_host(-K.data, rng.normal(size=ctx.n_dof))
     assert sol.last['state'] == 2
@@ -87,6 +87,57 @@ def test_pcg_edge_cases(fep):
     s2.close()
     sol.close()
     ctx.close()
+
+
+@pytest.mark.parametrize('et,n', [('P1', 48), ('P2', 12), ('Q1', 24)])
+def test_multigrid_pcg_matches_sparse_direct(fep, et, n):
+    """Hierarchy from K_elast, solve with the tangent of a plastic state (coarse operators lag behind on purpose)."""
+    mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
+    assert r['n_smooth'] + r['n_apex'] > 0
+    K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
+    sol = fep.KrylovSolver(ctx, qf)
+    with pytest.raises(fep.FepError, match='call order'):
+        sol.solve_host(r['K'], np.ones(ctx.n_dof), precond='amg')
+    levels = sol.setup_amg(K_el, mesh['coordinates'], coarse_nodes=30)
+    assert len(levels) >= 3 and levels[0][0] == ctx.n_dof and levels[-1][0] <= 3 * 200
+    b = rng.normal(size=ctx.n_dof)
+    for K in (K_el, r['K']):
+        x = sol.solve_host(K, b, rtol=1e-12)
+        it_amg = sol.last['iters']
+        assert sol.last['state'] == 1 and sol.last['precond'] == 'amg' and 0 < it_amg < 200
+        ref = np.zeros(ctx.n_dof)
+        ref[qf] = sspl.spsolve(K[qf][:, qf].tocsc(), b[qf])
+        assert np.all(x[~qf] == 0.0) and relerr(x, ref) <= 1e-8
+        assert np.linalg.norm((K @ x - b)[qf]) <= 1e-10 * np.linalg.norm(b[qf])
+        assert np.array_equal(x, sol.solve_host(K, b, rtol=1e-12))                      # reproducible
+        sol.solve_host(K, b, rtol=1e-12, precond='jacobi')
+        assert sol.last['state'] == 1 and sol.last['iters'] > 2 * it_amg
+    # zero right-hand side, breakdown on a negative definite matrix
+    assert np.all(sol.solve_host(K_el, np.where(qf, 0.0, 1.0)) == 0.0) and sol.last['iters'] == 0
+    sol.solve_host(-K_el.data, b)
+    assert sol.last['state'] == 2
+    sol.close()
+    ctx.close()
+
+
+def test_drivers_with_multigrid_solver(fep):
+    from conftest import load_golden
+    g = load_golden('dp_p1_level1_trace')
+    h = fep.solve_strip_footing('P1', level=1, linear_solver='amg')
+    assert len(h['zeta']) == 16 and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
+    for k in range(16):
+        assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-9, k
+    # coarse operators are those of K_elast: ~40 iterations while the plastic zone is small, more near collapse
+    assert h['counts'][-1] == (599, 171) and min(h['pcg_iters']) < 60 and max(h['pcg_iters']) < 5000
+    t = load_golden('tsx')
+    h = fep.solve_tsx_tunnel(t['coord'], t['elem'], 'P1', linear_solver='amg')
+    assert len(h['zeta']) == 17 and h['n_plast'] == [0] * 13 + [1, 1, 2, 3]
+    assert relerr(h['U'][-1], t['p1_U_final']) <= 1e-9
+    a = fep.solve_strip_footing('P1', n_cells=48, max_steps=6)
+    b = fep.solve_strip_footing('P1', n_cells=48, max_steps=6, linear_solver='amg')
+    assert a['zeta'] == b['zeta'] and a['counts'] == b['counts']
+    for k in range(6):
+        assert relerr(a['U'][k], b['U'][k]) <= 1e-9, k
 
 
 def test_solver_rejects_foreign_patterns(fep):

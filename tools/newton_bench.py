@@ -17,7 +17,7 @@ ap.add_argument('--n', type=int, default=708)
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--element', default='P1')
 ap.add_argument('--rtol', type=float, default=1e-10)
-ap.add_argument('--solver', default='pcg')
+ap.add_argument('--solver', default='amg', help='pcg (block-Jacobi CG) | amg (multigrid-preconditioned CG) | direct')
 a = ap.parse_args()
 
 lines = []
@@ -29,5 +29,5 @@ it = h['pcg_iters'] or []
 print(json.dumps({'n_cells': a.n, 'element': a.element, 'elements': int(h['mesh']['elements'].shape[1]),
                   'accepted_steps': len(h['zeta']), 'hot_path_calls': h['n_calls'], 'newton_its': h['newton_its'],
                   'wall_s': t, 'linear_solves': len(it), 'pcg_iters_total': int(sum(it)),
-                  'pcg_iters_max': int(max(it)) if it else None, 'zeta': h['zeta'], 'pressure': h['pressure'],
+                  'pcg_iters_max': int(max(it)) if it else None, 'pcg_iters': [int(v) for v in it], 'zeta': h['zeta'], 'pressure': h['pressure'],
                   'counts': h['counts']}))
