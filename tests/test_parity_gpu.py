@@ -512,6 +512,46 @@ def test_p2_one_million_points_divergence_stress(fep):
     ctx.close()
 
 
+def test_config5_full_size_p2_properties(fep):
+    """BASELINE configs[4] at its full size on ONE GPU: 3 998 792 P2 elements = 27 991 544 integration points,
+    branches i.i.d. per point.  The oracle cannot run this (and the reference even less); checked are the sampled
+    points against the oracle's map and size-independent properties of K and F (symmetry and the rigid translations
+    through products, the force balance, the fused against the unfused route)."""
+    N = 1414
+    mesh = fep.square_mesh(N, 'P2', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n_e = elem.shape[1]
+    n_int = n_e * 7
+    assert (n_e, n_int, coord.shape[1]) == (3998792, 27991544, 8003241)
+    sh, bu, eta, c = dp_materials(1)
+    rng = np.random.default_rng(23)
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10), -1.2e-4 * y]) + rng.normal(0, 2.5e-6 * 270 / N, size=coord.shape)
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh[0], bu[0], eta[0], c[0])
+    r = ctx.step(U, None, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    n_el = n_int - r['n_smooth'] - r['n_apex']
+    assert min(n_el, r['n_smooth'], r['n_apex']) > 0.1 * n_int
+    assert (np.diff(r['ind_p'][:200000].astype(np.int8)) != 0).mean() > 0.2      # divergence inside waves
+    sel = rng.choice(n_int, 5000, replace=False)
+    one = np.ones(sel.size)
+    o = orc.return_map(r['E'][:, sel], None, sh[0] * one, bu[0] * one, eta[0] * one, c[0] * one)
+    assert np.array_equal(o['ind_p'], r['ind_p'][sel])
+    assert relerr(r['s'][:, sel], o['s']) <= TOL_PT and relerr(r['ds'][:, sel], o['ds']) <= TOL_PT
+    K, F = r['K'], r['F']
+    assert K.nnz == ctx.nnz == 367979364
+    kmax = np.abs(K.data).max()
+    u, v = rng.normal(size=ctx.n_dof), rng.normal(size=ctx.n_dof)
+    Ku, Kv = K @ u, K @ v
+    assert abs(v @ Ku - u @ Kv) <= 1e-11 * (np.abs(v) @ np.abs(Ku))             # symmetry
+    for t in ([1.0, 0.0], [0.0, 1.0]):
+        assert np.abs(K @ np.tile(t, coord.shape[1])).max() <= 1e-9 * kmax          # translations in the kernel
+    assert abs(F[0::2].sum()) <= 1e-9 * np.abs(F).sum() and abs(F[1::2].sum()) <= 1e-9 * np.abs(F).sum()
+    K2, F2 = ctx.assemble(r['ds'], r['s'])
+    assert np.array_equal(K2.data, K.data) and np.array_equal(F2, F)
+    ctx.close()
+
+
 # ---- special values and wide parameter ranges of the return map --------------------------------------
 def test_return_map_special_values_vs_oracle(fep):
     """Zero strain, points exactly on the switching surfaces, pure volumetric / pure deviatoric strains,
