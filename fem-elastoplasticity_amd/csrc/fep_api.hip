@@ -4,6 +4,7 @@
 #include "fep_kernels.hip.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -814,6 +815,15 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
                                         (size_t)c->tile * 3 * sizeof(double2));
             const int n_wg = c->n_wg_p1;
             const int chunk = (n_wg + 7) / 8;
+            static const bool verbose = std::getenv("FEP_VERBOSE") != nullptr;
+            if (verbose) {
+                static bool once = false;
+                if (!once) {
+                    once = true;
+                    std::fprintf(stderr, "[fep] p1 assembly kernel: %d tiles of <= %d blocks, staged elements <= %d, codes <= %d, "
+                                 "LDS %zu bytes per workgroup\n", n_wg, c->tile, c->lds_L, c->lds_C, lds);
+                }
+            }
 #define NODE_LDS3(TPB, RNG, EPT, PK)                                                                                     \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \

@@ -118,7 +118,9 @@ int fep_ctx_geometry_host(fep_ctx* ctx, double* dphi1_h, double* dphi2_h, double
  * also those that are numerically zero — the reference's SciPy product drops them). */
 int fep_ctx_pattern_host(const fep_ctx* ctx, int32_t* indptr_h /* n_dof+1 */, int32_t* indices_h /* nnz */);
 
-/* Per-point material parameters (n_int each): shear, bulk (DP:972-973), eta, c (DP:983-984). */
+/* Per-point material parameters (n_int each): shear, bulk (DP:972-973), eta, c (DP:983-984).  When each of the four
+ * arrays is constant over the mesh (the reference's demos) the kernels take the constants as arguments and do not
+ * read the arrays; results are bitwise the same either way (FEP_NO_UNIFORM=1 in the environment disables it). */
 int fep_ctx_set_materials_host(fep_ctx* ctx, const double* shear_h, const double* bulk_h,
                                const double* eta_h, const double* c_h);
 /* Device pointers of the context's static per-point arrays (for the mesh-free entry points):
