@@ -436,7 +436,6 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         CK(upload(&c->perm2, perm2.data(), (int64_t)perm2.size()));
         CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
         {   // per-workgroup (`tile` consecutive blocks) sorted unique element lists + local gather codes
-            if (const char* tv = std::getenv("FEP_NODE_TILE")) { const int t = std::atoi(tv); if (t == 128 || t == 256 || t == 512) c->tile = t; }
             const int64_t TILE = c->tile;
             // tiles = runs of WHOLE nodes with at most TILE blocks (a node's blocks are consecutive ids)
             std::vector<int32_t> tstart{0};
@@ -842,7 +841,7 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
         if (c->p1_rng) { if (one) NODE_LDS2(TPB, true, 1); else NODE_LDS2(TPB, true, 2); }                               \
         else { if (one) NODE_LDS2(TPB, false, 1); else NODE_LDS2(TPB, false, 2); }                                       \
     } while (0)
-            if (c->tile == 128) NODE_LDS(128); else if (c->tile == 512) NODE_LDS(512); else NODE_LDS(256);
+            NODE_LDS(256);                 // tiles of 128 / 512 blocks were measured slower (profiles/r01_ablation.md)
 #undef NODE_LDS
 #undef NODE_LDS2
 #undef NODE_LDS3

@@ -19,7 +19,12 @@ N = int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 mix = sys.argv[4] if len(sys.argv) > 4 else 'bands'
 t0 = time.time()
-mesh = fep.square_mesh(N, t, 10)
+if t == 'P4':                       # P4 meshes come from the midpoint generator (TSX:1354-1505) on a P1 mesh
+    m1 = fep.square_mesh(N, 'P1', 10)
+    mp = fep.create_midpoints_P4(m1['coordinates'], m1['elements'])
+    mesh = {'elements': np.asarray(mp['elem_ext'], dtype=np.int64), 'coordinates': mp['coord_ext']}
+else:
+    mesh = fep.square_mesh(N, t, 10)
 ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
 t_setup = time.time() - t0
 ctx.set_materials(*bench.dp_materials())
