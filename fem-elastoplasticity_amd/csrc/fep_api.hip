@@ -563,7 +563,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
                 }
             }
         }
-        CK(dmalloc(&c->geo, 8 * n_e));
+        CK(dmalloc(&c->geo, 6 * n_e));
         {
             for (int a = 0; a < 3; ++a) { c->p1tab.h1[a] = dhatp1_h[a]; c->p1tab.h2[a] = dhatp2_h[a]; }
             c->p1tab.wf = wf_h[0];

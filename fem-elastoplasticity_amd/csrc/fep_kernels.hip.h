@@ -220,15 +220,15 @@ geometry_kernel(int64_t n_e, int64_t n_n, const int32_t* __restrict__ elem, cons
     }
     weight[k] = fabs(det) * tw[q];                       // DP:585
     if (det_out) det_out[k] = det;
-    if (NP == 3 && NQ == 1 && geo) {                     // AoS record of the P1 fast path: d1[3], d2[3], w, 0
-        double* g = geo + k * 8;
-        for (int a = 0; a < NP; ++a) {
+    if (NP == 3 && NQ == 1 && geo) {     // 48-byte AoS record of the P1 fast path: d1[0], d1[1], d2[0], d2[1], w, 0;
+        double* g = geo + k * 6;         // the third node's gradient is -(first + second) (partition of unity)
+        for (int a = 0; a < 2; ++a) {
             const double h1 = t1[a * NQ + q], h2 = t2[a * NQ + q];
             g[a] = i11 * h1 + i12 * h2;
-            g[3 + a] = i21 * h1 + i22 * h2;
+            g[2 + a] = i21 * h1 + i22 * h2;
         }
-        g[6] = fabs(det) * tw[q];
-        g[7] = 0.0;
+        g[4] = fabs(det) * tw[q];
+        g[5] = 0.0;
     }
 }
 
@@ -549,7 +549,7 @@ __device__ __forceinline__ void p1_geometry(const P1Tab& tab, const double2 c0, 
 //                     order of `perm2` (a3, a4); the lane that owns the diagonal block of a node also
 //                     sums the node's internal force  w * B_a^T s  (a5).  No atomics, no COO buffer.
 //
-//   geo[e*8 + {0,1,2}] = dphi_1 of the 3 nodes, {3,4,5} = dphi_2, [6] = weight (64-byte record)
+//   geo[e*6 + {0,1}] = dphi_1 of nodes 0, 1, {2,3} = dphi_2, [4] = weight (48-byte record; node 2 = -(0 + 1))
 //   perm2[t] = e*16 + a*4 + b ;  meta = (deg << 16) | (diag << 15) | slot
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -604,8 +604,9 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
         const uint32_t code = (uint32_t)perm2[t];
         const int64_t e = code >> 4;
         const int a = (code >> 2) & 3, b = code & 3;
-        const double* g = geo + e * 8;
-        const double a1 = g[a], a2 = g[3 + a], b1 = g[b], b2 = g[3 + b], w = g[6];
+        const double* g = geo + e * 6;
+        const double d1[3] = {g[0], g[1], -(g[0] + g[1])}, d2[3] = {g[2], g[3], -(g[2] + g[3])};
+        const double a1 = d1[a], a2 = d2[a], b1 = d1[b], b2 = d2[b], w = g[4];
         if (DS) {
             const double D00 = DS[e], D01 = DS[n_e + e], D02 = DS[2 * n_e + e];
             const double D11 = DS[4 * n_e + e], D12 = DS[5 * n_e + e], D22 = DS[8 * n_e + e];
@@ -714,14 +715,14 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // (2) operand loads.  Wave-uniform guard: a wave whose 64 slots all lie past the list issues nothing
     // (with L = 150 of 256 slots that is one wave in four: the kernel's time follows its vector-memory
     // instruction count); inside a wave every lane loads (slots past the list repeat a valid element).
-    double2 g0[EPT], g1[EPT], g2[EPT], g3[EPT];        // 64-byte geometry record (4 x 16-byte loads; the SoA dphi
+    double2 g0[EPT], g1[EPT], g2[EPT];                  // 48-byte geometry record (3 x 16-byte loads; the SoA dphi
     double dv[EPT][6], sv[EPT][3];                      // arrays as 7 x 8-byte loads measured 5-10 us slower)
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         if (r * TPB + (int)(threadIdx.x & ~63u) >= L) continue;
         const int64_t e = el[r];
-        const double2* g = reinterpret_cast<const double2*>(geo + e * 8);
-        g0[r] = g[0]; g1[r] = g[1]; g2[r] = g[2]; g3[r] = g[3];
+        const double2* g = reinterpret_cast<const double2*>(geo + e * 6);
+        g0[r] = g[0]; g1[r] = g[1]; g2[r] = g[2];
         if (DS) {
             dv[r][0] = DS[e]; dv[r][1] = DS[n_e + e]; dv[r][2] = DS[2 * n_e + e];
             dv[r][3] = DS[4 * n_e + e]; dv[r][4] = DS[5 * n_e + e]; dv[r][5] = DS[8 * n_e + e];
@@ -762,9 +763,9 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     for (int r = 0; r < EPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
         if (i < L) {
-            const double w = g3[r].x;
-            rec[9 * L + i] = g0[r].x;  rec[10 * L + i] = g0[r].y; rec[11 * L + i] = g1[r].x;     // d1[0..2]
-            rec[12 * L + i] = g1[r].y; rec[13 * L + i] = g2[r].x; rec[14 * L + i] = g2[r].y;     // d2[0..2]
+            const double w = g2[r].x;
+            rec[9 * L + i] = g0[r].x;  rec[10 * L + i] = g0[r].y; rec[11 * L + i] = -(g0[r].x + g0[r].y);   // d1[0..2]
+            rec[12 * L + i] = g1[r].x; rec[13 * L + i] = g1[r].y; rec[14 * L + i] = -(g1[r].x + g1[r].y);   // d2[0..2]
             if (DS) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) rec[k * L + i] = w * dv[r][k];
