@@ -66,3 +66,33 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'oracle' not in txt.replace('no oracle', ''), f
+
+
+def test_aggregate_host_without_gpu(built):
+    """fep_aggregate_host is pure host code: every node lands in exactly one aggregate, aggregates are connected
+    neighbourhoods of a root (pass 1) plus attached leftovers (pass 2)."""
+    import numpy as np
+    import scipy.sparse as ssp
+    n = 13
+    idx = np.arange(n * n).reshape(n, n)
+    rows, cols = [], []
+    for di, dj in ((0, 0), (0, 1), (1, 0), (0, -1), (-1, 0), (1, 1), (-1, -1)):           # P1 node graph (7-point)
+        a = idx[max(0, -di):n - max(0, di), max(0, -dj):n - max(0, dj)]
+        b = idx[max(0, di):n - max(0, -di), max(0, dj):n - max(0, -dj)]
+        rows.append(a.ravel()); cols.append(b.ravel())
+    G = ssp.csr_matrix((np.ones(sum(r.size for r in rows)), (np.concatenate(rows), np.concatenate(cols))), shape=(n * n, n * n))
+    ip, ix = G.indptr.astype(np.int32), G.indices.astype(np.int32)
+    agg = np.full(n * n, -7, dtype=np.int32)
+    na = ctypes.c_int64()
+    rc = built.lib().fep_aggregate_host(n * n, ip.ctypes.data_as(ctypes.c_void_p), ix.ctypes.data_as(ctypes.c_void_p),
+                                        agg.ctypes.data_as(ctypes.c_void_p), ctypes.byref(na))
+    assert rc == 0 and 0 < na.value < n * n // 3
+    assert agg.min() == 0 and agg.max() == na.value - 1 and np.unique(agg).size == na.value
+    A = ssp.csr_matrix((np.ones(n * n), (np.arange(n * n), agg)), shape=(n * n, na.value))
+    sizes = np.asarray(A.sum(axis=0)).ravel()
+    assert sizes.min() >= 1 and sizes.max() <= 2 * 7
+    # connected: the sub-graph of every aggregate has one component
+    for a in range(na.value):
+        m = np.flatnonzero(agg == a)
+        assert ssp.csgraph.connected_components(G[m][:, m], directed=False)[0] == 1
+    assert built.lib().fep_aggregate_host(0, None, None, None, None) == -1
