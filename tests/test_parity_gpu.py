@@ -512,6 +512,47 @@ def test_p2_one_million_points_divergence_stress(fep):
     ctx.close()
 
 
+@pytest.mark.parametrize('numbering', ['rows', 'random'])
+def test_unstructured_delaunay_mesh_vs_oracle(fep, p1_route, numbering):
+    """General connectivity: Delaunay triangulation of jittered points (node degrees 4..10, arbitrary orientation —
+    the reference takes |det|), nodes and elements in generator order or randomly renumbered."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(4)
+    M = 36
+    g = np.stack(np.meshgrid(np.arange(M + 1), np.arange(M + 1), indexing='xy')).reshape(2, -1).astype(float)
+    inner = (g[0] > 0) & (g[0] < M) & (g[1] > 0) & (g[1] < M)
+    g[:, inner] += rng.uniform(-0.35, 0.35, size=(2, int(inner.sum())))
+    coord = g * (10.0 / M)
+    if numbering == 'random':
+        coord = coord[:, rng.permutation(coord.shape[1])]
+    elem = Delaunay(coord.T).simplices.T.astype(np.int64)
+    if numbering == 'random':
+        elem = elem[:, rng.permutation(elem.shape[1])]
+        elem = np.where(rng.random(elem.shape[1]) < 0.5, elem, elem[[0, 2, 1]])       # mixed orientations
+    n_e = elem.shape[1]
+    deg = np.bincount(elem.ravel())
+    assert deg.min() >= 1 and deg.max() >= 8
+    d1, d2, wf = fep.element_tables('P1')
+    sh, bu, eta, c = dp_materials(n_e)
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    Ep = rng.normal(0, 5e-6, size=(4, n_e))
+    ctx = fep.MeshContext(elem, coord, d1, d2, wf)
+    ctx.set_materials(sh, bu, eta, c)
+    ep = Ep.copy()
+    r = ctx.step(U, ep, apply_plastic_strain=True, want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)
+    ep_o = Ep.copy()
+    E, cp, K_t, F = orc.hot_path(U, ep_o, dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=sh, bulk=bu,
+                                                eta=eta, c=c), apply_plastic_strain=True)
+    assert cp['n_smooth'] > 0 and cp['n_apex'] > 0
+    assert (r['n_smooth'], r['n_apex']) == (cp['n_smooth'], cp['n_apex']) and np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['s'], cp['s']) <= TOL_PT and relerr(r['ds'], cp['ds']) <= TOL_PT and relerr(ep, ep_o) <= TOL_PT
+    assert np.abs((r['K'] - K_t).data).max() <= TOL_K * np.abs(K_t.data).max()
+    assert relerr(r['F'], F) <= TOL_K
+    ctx.close()
+
+
 def test_config5_full_size_p2_properties(fep):
     """BASELINE configs[4] at its full size on ONE GPU: 3 998 792 P2 elements = 27 991 544 integration points,
     branches i.i.d. per point.  The oracle cannot run this (and the reference even less); checked are the sampled
