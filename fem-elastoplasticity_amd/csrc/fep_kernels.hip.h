@@ -755,7 +755,8 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
 #pragma unroll
     for (int r = 0; r < CWPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
-        cd[r] = codes_w[i < CW ? i : 0];
+        cd[r] = 0u;
+        if (r * TPB + (int)(threadIdx.x & ~63u) < CW) cd[r] = codes_w[i < CW ? i : 0];   // wave-uniform: idle waves issue nothing
     }
     // (4) operands -> LDS
     uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);

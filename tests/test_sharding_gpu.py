@@ -95,3 +95,33 @@ def test_step_dev_is_graph_capturable_and_device_resident(fep):
     assert np.array_equal(ind.cpu().numpy().astype(bool), ref['ind_p'])
     assert tuple(cnt.cpu().tolist()) == (ref['n_smooth'], ref['n_apex'])
     ctx.close()
+
+
+def test_contexts_and_solvers_release_their_device_memory(fep):
+    """Create / destroy cycles (all routes' tables, solver hierarchy) leave the device allocation where it was."""
+    import torch
+    torch.cuda.synchronize()
+
+    def used():
+        free, total = torch.cuda.mem_get_info(0)
+        return total - free
+
+    def cycle():
+        for et, n in (('P1', 64), ('P2', 24), ('Q1', 40)):
+            mesh = fep.square_mesh(n, et, 10)
+            ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
+            ctx.set_materials(*[v[0] for v in dp_materials(1)])
+            K = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
+            sol = fep.KrylovSolver(ctx, mesh['Q'].flatten(order='F'))
+            sol.setup_amg(K, mesh['coordinates'], coarse_nodes=20)
+            sol.solve_host(K, np.ones(ctx.n_dof), rtol=1e-8)
+            sol.close()
+            ctx.close()
+
+    cycle()
+    torch.cuda.empty_cache()
+    base = used()
+    for _ in range(5):
+        cycle()
+    torch.cuda.empty_cache()
+    assert used() - base <= 8 << 20          # allocator granularity, not a per-cycle leak (one cycle allocates ~100 MB)
