@@ -636,9 +636,10 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
         CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
         const char* ge = std::getenv("FEP_ELEM_GEO");
-        // measured on MI355X (1 M elements): Q1 0.204 vs 0.218 ms with recomputed geometry; P2 0.471 vs 0.430 ms and
-        // Q2 0.394 vs 0.391 ms (the coordinate staging costs LDS, hence a resident workgroup)
-        c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : elem_type == FEP_Q1;
+        // measured on MI355X (1 M elements, element kernel alone): recomputed geometry wins for Q1 (0.204 vs 0.218 ms) and
+        // Q2 (0.344 vs 0.391 ms with 24 instead of 28 elements per workgroup, so that three workgroups still fit a CU) and
+        // loses for P2 (0.50 vs 0.47 ms at 28 / 32 elements per workgroup)
+        c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : (elem_type == FEP_Q1 || elem_type == FEP_Q2);
     }
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
@@ -662,11 +663,11 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
         int eb = 1;
         switch (elem_type) {
-            case FEP_P1: eb = ElemCfg<3, 1>::EB; break;
-            case FEP_P2: eb = ElemCfg<6, 7>::EB; break;
-            case FEP_Q1: eb = ElemCfg<4, 4>::EB; break;
-            case FEP_Q2: eb = ElemCfg<8, 9>::EB; break;
-            case FEP_P4: eb = ElemCfg<15, 12>::EB; break;
+            case FEP_P1: eb = c->elem_geo ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB; break;
+            case FEP_P2: eb = c->elem_geo ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB; break;
+            case FEP_Q1: eb = c->elem_geo ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB; break;
+            case FEP_Q2: eb = c->elem_geo ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB; break;
+            case FEP_P4: eb = c->elem_geo ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB; break;
         }
         c->n_count_blocks = (int)grid_for(n_e, eb);
     }
@@ -763,10 +764,10 @@ template <int NP, int NQ, bool FROM_U>
 static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept,
                           double* eout, double* s, double* ds, uint8_t* indp, uint2* blk_counts,
                           double* Kc, double* fe) {
-    constexpr int EB = ElemCfg<NP, NQ>::EB;
-    static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
+    static_assert(ElemCfg<NP, NQ, false>::EB * (NQ > NP ? NQ : NP) <= kBlock, "one pass per phase");
 #define ELEM_LAUNCH(GEO)                                                                                                \
-    hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO>), dim3(grid_for(c->n_e, EB)), dim3(kBlock), 0, st, c->n_e,    \
+    hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO>), dim3(grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)),          \
+                       dim3(kBlock), 0, st, c->n_e,                                                                     \
                        c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,       \
                        c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts, Kc, fe)
     if (c->elem_geo) ELEM_LAUNCH(true); else ELEM_LAUNCH(false);

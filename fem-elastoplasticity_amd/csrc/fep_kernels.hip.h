@@ -282,9 +282,12 @@ inline __host__ __device__ void sym_block_index(int n_p, int a, int b, int& idx,
 }
 inline __host__ __device__ int sym_block_count(int n_p) { return (n_p / 2 + 1) * n_p; }   // upper bound on idx + 1
 
-template <int NP, int NQ> struct ElemCfg {
+template <int NP, int NQ, bool GEO = false> struct ElemCfg {
     static constexpr int maxpq = NP > NQ ? NP : NQ;
-    static constexpr int EB = (kBlock / maxpq) >= 64 ? 64 : ((kBlock / maxpq) >= 32 ? 32 : (kBlock / maxpq));
+    static constexpr int EB0 = (kBlock / maxpq) >= 64 ? 64 : ((kBlock / maxpq) >= 32 ? 32 : (kBlock / maxpq));
+    // with the coordinate staging of GEO the big elements take fewer per workgroup, so that the LDS still admits
+    // as many resident workgroups as without it (P2: 4 per CU, Q2: 3)
+    static constexpr int EB = !GEO ? EB0 : (NP == 6 && NQ == 7) ? 28 : (NP == 8 && NQ == 9) ? 24 : EB0;
     static constexpr int NQS = NQ | 1;                  // odd LDS stride: conflict-free ds_read_b64 over elements
     static constexpr int NPTS = EB * NQS;
 };
@@ -305,7 +308,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                uint2* blk_counts,
                // outputs of phase 2
                double* __restrict__ Kc, double* __restrict__ fe) {
-    using C = ElemCfg<NP, NQ>;
+    using C = ElemCfg<NP, NQ, GEO>;
     constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
     constexpr int NJ = NP / 2 + 1;                   // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
     __shared__ double d1s[NP][NPTS], d2s[NP][NPTS];
