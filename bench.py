@@ -191,9 +191,9 @@ def main():
         # each kernel against its OWN minimal HBM bytes: point = elem ids 12 + ep 32
         # + coordinates/displacements 32 (16 B per node, ~2 elements per node) + s 32 + ds 72 + ind_p 1 = 181 B (the
         # materials are constant over the mesh here and are not read: 32 B less than the general case);
-        # assembly = ds 48 (6 of 9 rows) + s 24 + geometry 56 + descriptors/codes 32 + CSR values 8*nnz/n + force 16*n_n/n
+        # assembly = ds 48 (6 of 9 rows) + s 24 + geometry record 48 + descriptors/codes 32 + CSR values 8*nnz/n + force 16*n_n/n
         b_point = 181.0 * n_int
-        b_node = (48 + 24 + 56 + 32) * n_int + 8.0 * ctx.nnz + 8.0 * ctx.n_dof
+        b_node = (48 + 24 + 48 + 32) * n_int + 8.0 * ctx.nnz + 8.0 * ctx.n_dof
         per_kernel = {'p1_point_kernel': {'bytes': b_point, 'GBps': b_point / (kms['element'] * 1e-3) / 1e9,
                                           'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                       'p1_node_kernel': {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
