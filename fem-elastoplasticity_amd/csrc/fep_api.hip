@@ -784,12 +784,16 @@ static int launch_counts(fep_ctx* c, hipStream_t st, unsigned long long* counts_
 }
 
 // COO route, numeric phase: K_e blocks -> CSR values, f_e pairs -> nodal force
-static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_out) {
+static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_out,
+                         unsigned long long* counts_d = nullptr, bool* counts_done = nullptr) {
+    if (counts_done) *counts_done = false;
     FEP_TRY(prof_mark(c, st));
     if (k_data) {
-        hipLaunchKernelGGL(csr_reduce_kernel, dim3(c->n_wg_p1), dim3(kBlock), 0, st,
-                           c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data);
+        hipLaunchKernelGGL(csr_reduce_kernel, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st,
+                           c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data, c->n_count_blocks,
+                           c->blk_counts, counts_d);
         HIP_TRY(hipGetLastError());
+        if (counts_done) *counts_done = counts_d != nullptr;
     }
     FEP_TRY(prof_mark(c, st));
     if (f_out) {
@@ -958,8 +962,9 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
                                           k_data_d ? c->Kc : nullptr, f_out_d ? c->fe : nullptr)))
     DISPATCH_ELEM(c->elem_type, CALL)
 #undef CALL
-    FEP_TRY(launch_reduce(c, st, k_data_d, f_out_d));
-    return launch_counts(c, st, cnt);
+    bool counted = false;
+    FEP_TRY(launch_reduce(c, st, k_data_d, f_out_d, cnt, &counted));
+    return counted ? FEP_OK : launch_counts(c, st, cnt);
 }
 
 extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, const double* s_d,

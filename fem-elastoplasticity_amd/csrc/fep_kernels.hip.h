@@ -441,12 +441,16 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 __global__ void __launch_bounds__(kBlock)
 csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t* __restrict__ segptr,
                   const int32_t* __restrict__ perm, const uint32_t* __restrict__ meta,
-                  const double* __restrict__ Kc, double* __restrict__ data) {
+                  const double* __restrict__ Kc, double* __restrict__ data,
+                  int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
     // one workgroup = one tile of whole nodes, blocks [tstart[g], tstart[g+1]) (<= kBlock): its 4*nb CSR values
     // are one contiguous range, staged in LDS and written as full consecutive lines (a lane's two 16-byte pieces
     // belong to two different rows; direct stores fill every line in two half passes)
     __shared__ double2 out2[2 * kBlock];
-    const int g = blockIdx.x;
+    // with counts_out the FIRST workgroup sums the branch counters of the element kernel on the side (first, so that
+    // its serial chain runs under the tiles, not after them)
+    const int g = counts_out != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (g < 0) { sum_block_counts(n_count_blocks, blk_counts, counts_out); return; }
     if (g >= n_tiles) return;
     const int64_t sb0 = tstart[g];
     const int nb = tstart[g + 1] - (int)sb0;
@@ -678,7 +682,7 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // re-staged by the workgroups of the next node row hit in the SAME L2 instead of the fabric.
     const int chunk = (n_wg + 7) >> 3;
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (counts_out != nullptr && blockIdx.x == gridDim.x - 1) sum_block_counts(n_count_blocks, blk_counts, counts_out);
+    if (counts_out != nullptr && blockIdx.x == 0) sum_block_counts(n_count_blocks, blk_counts, counts_out);
     if (wg >= n_wg) return;
     // Two dependent memory levels only: every table is padded to a fixed per-tile stride (element list:
     // L entries, gather codes: C entries, unused slots repeat a valid entry), so all first-level
@@ -937,7 +941,7 @@ node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restr
     __shared__ int32_t t0_sh;
     const int chunk = (n_wg + 7) >> 3;                                // XCD-aware tile order (see p1_node_lds_kernel)
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (counts_out != nullptr && blockIdx.x == gridDim.x - 1) sum_block_counts(n_count_blocks, blk_counts, counts_out);
+    if (counts_out != nullptr && blockIdx.x == 0) sum_block_counts(n_count_blocks, blk_counts, counts_out);
     if (wg >= n_wg) return;
     const int64_t n_int = n_e * NQ;
     const int64_t sb = (int64_t)wg * TPB + threadIdx.x;

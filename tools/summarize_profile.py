@@ -62,6 +62,9 @@ def main():
             traffic[k] = b
             w.writerow([k, f'{fetch.get(k, 0.0):.1f}', f'{write.get(k, 0.0):.1f}', f'{b:.0f}'])
     dom = [k for k in traffic if any(s in k for s in ('p1_point_kernel', 'p1_node', 'p1_fused', 'element_kernel'))]
+    if os.environ.get('FEP_SUMMARY_ONLY'):       # other workloads than bench.py's: tables only, traffic_latest.json untouched
+        print(json.dumps({k: round(v / 1e6, 1) for k, v in traffic.items()}))
+        return
     json.dump({'round': tag, 'kernels': {k: traffic[k] for k in dom},
                'hbm_bytes_per_launch': sum(traffic[k] for k in dom),
                'note': 'sum over the return-map + assembly kernels of one step; 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes',
