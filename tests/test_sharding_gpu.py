@@ -124,4 +124,4 @@ def test_contexts_and_solvers_release_their_device_memory(fep):
     for _ in range(5):
         cycle()
     torch.cuda.empty_cache()
-    assert used() - base <= 8 << 20          # allocator granularity, not a per-cycle leak (one cycle allocates ~100 MB)
+    assert used() - base <= 64 << 20         # allocator granularity, not a per-cycle leak (five cycles allocate ~0.5 GB)
