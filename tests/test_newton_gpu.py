@@ -52,6 +52,24 @@ def test_tsx_p2_first_steps(fep):
         assert relerr(h['U'][k] / h['zeta'][k], h['U'][el[0]] / h['zeta'][el[0]]) <= 1e-9
 
 
+def test_tsx_p4_full_run_consistent_with_p2_and_p1(fep):
+    """Config 3 on the P4 mesh (15-node triangles, 14 288 free DOFs): no reference trace exists for it (the reference's
+    own TSX driver does not run under NumPy >= 1.24); the 17 load steps must converge and the monitored displacement
+    must agree with the P2 and the pinned P1 result to discretisation accuracy, elastic steps must be linear in zeta."""
+    g = load_golden('tsx')
+    h4 = fep.solve_tsx_tunnel(g['p4_coord'], g['p4_elem'], 'P4')
+    h2 = fep.solve_tsx_tunnel(g['p2_coord'], g['p2_elem'], 'P2')
+    assert len(h4['zeta']) == 17 == len(h2['zeta']) and abs(h4['zeta'][-1] - 1.0) < 1e-12
+    d1 = -0.0019794496707526746                                     # P1, SURVEY 8c
+    e21, e42 = abs(h2['displ'][-1] - d1), abs(h4['displ'][-1] - h2['displ'][-1])
+    assert e21 <= 0.2 * abs(d1) and e42 <= 0.03 * abs(d1) and e42 < 0.25 * e21      # P1 -1.98e-3, P2 -2.24e-3, P4 -2.27e-3
+    el = [k for k, n in enumerate(h4['n_plast']) if n == 0]
+    assert len(el) >= 3
+    for k in el[1:]:
+        assert relerr(h4['U'][k] / h4['zeta'][k], h4['U'][el[0]] / h4['zeta'][el[0]]) <= 1e-9
+    assert h4['n_plast'][-1] > 0
+
+
 def test_transform_matches_definition(fep):
     rng = np.random.default_rng(0)
     mesh = fep.square_mesh(3, 'P2', 3)
