@@ -164,3 +164,33 @@ def test_el_p1_K_pins(level, nnz, trace, frob):
     assert abs(np.sqrt((K.data ** 2).sum()) - frob) <= 1e-12 * frob
     assert abs(w.sum() - 75.0) <= 1e-12 * 75
     assert relerr(K @ np.cos(np.arange(K.shape[0]) * 0.37), g[f'l{level}_Kx']) <= 1e-13
+
+
+def _tangent_by_differences(fn, e, h=1e-9):
+    n = e.shape[1]
+    fd = np.zeros((9, n))
+    for j in range(3):
+        de = np.zeros((3, n))
+        de[j] = h
+        sp, sm = fn(e + de)['s'], fn(e - de)['s']
+        for i in range(3):
+            fd[3 * i + j] = (sp[i] - sm[i]) / (2 * h)
+    return fd
+
+
+def test_ds_is_the_consistent_tangent_of_s():
+    """Independent of the reference: `ds` (DP:703-741) is d s[0:3] / d e on every branch (elastic: Hooke, smooth:
+    the cone's consistent tangent, apex: zero), checked by central differences with the plastic strain held fixed."""
+    from conftest import dp_materials
+    rng = np.random.default_rng(3)
+    n = 3000
+    sh, bu, eta, c = dp_materials(n)
+    e = rng.normal(0, 3e-4, size=(3, n))
+    e[0:2] += rng.normal(1e-4, 2e-4, size=(1, n))
+    ep = rng.normal(0, 2e-5, size=(4, n))
+    r = orc.return_map(e, ep.copy(), sh, bu, eta, c)
+    assert min((~r['ind_p']).sum(), r['n_smooth'], r['n_apex']) > 300
+    fd = _tangent_by_differences(lambda x: orc.return_map(x, ep.copy(), sh, bu, eta, c), e)
+    assert np.abs(fd - r['ds']).max() <= 1e-7 * np.abs(r['ds']).max()
+    D = r['ds'].reshape(3, 3, n)
+    assert np.array_equal(D, D.transpose(1, 0, 2))                   # symmetric (associated flow): K_tangent is too

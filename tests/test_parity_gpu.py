@@ -593,6 +593,28 @@ def test_config5_full_size_p2_properties(fep):
     ctx.close()
 
 
+def test_gpu_ds_is_the_consistent_tangent_of_gpu_s(fep):
+    """The kernel's `ds` against central differences of the kernel's own `s` (no oracle involved)."""
+    rng = np.random.default_rng(3)
+    n = 20000
+    sh, bu, eta, c = dp_materials(n)
+    e = rng.normal(0, 3e-4, size=(3, n))
+    e[0:2] += rng.normal(1e-4, 2e-4, size=(1, n))
+    ep = rng.normal(0, 2e-5, size=(4, n))
+    cc = fep.plasticity2d_dp.construct_constitutive_problem
+    r = cc(e, ep.copy(), sh, bu, eta, c)
+    assert min((~r['ind_p']).sum(), r['n_smooth'], r['n_apex']) > 2000
+    h = 1e-9
+    fd = np.zeros((9, n))
+    for j in range(3):
+        de = np.zeros((3, n))
+        de[j] = h
+        sp, sm = cc(e + de, ep.copy(), sh, bu, eta, c)['s'], cc(e - de, ep.copy(), sh, bu, eta, c)['s']
+        for i in range(3):
+            fd[3 * i + j] = (sp[i] - sm[i]) / (2 * h)
+    assert np.abs(fd - r['ds']).max() <= 1e-7 * np.abs(r['ds']).max()
+
+
 # ---- special values and wide parameter ranges of the return map --------------------------------------
 def test_return_map_special_values_vs_oracle(fep):
     """Zero strain, points exactly on the switching surfaces, pure volumetric / pure deviatoric strains,
