@@ -593,6 +593,34 @@ def test_config5_full_size_p2_properties(fep):
     ctx.close()
 
 
+@pytest.mark.parametrize('t,N', [('P1', 24), ('P2', 8), ('Q1', 12), ('Q2', 6)])
+def test_tangent_is_the_derivative_of_the_internal_force(fep, t, N):
+    """End to end without any checker: K_tangent(U) v equals the central difference of F(U + h v) (the Newton
+    linearisation DP:1050 / DP:1058 is consistent), on a state with all three branches."""
+    rng = np.random.default_rng(8)
+    mesh = fep.square_mesh(N, t, 10)
+    coord = mesh['coordinates']
+    ctx = fep.MeshContext(mesh['elements'], coord)
+    ctx.set_materials(*[v[0] for v in dp_materials(1)])
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    U = U.reshape(-1, order='F')
+    Ep = rng.normal(0, 5e-6, size=(4, ctx.n_int))
+    r = ctx.step(U, Ep, want=('K', 'F', 'ind_p'))
+    assert r['n_smooth'] > 0 and r['n_apex'] > 0 and r['n_smooth'] + r['n_apex'] < ctx.n_int
+    v = rng.normal(size=ctx.n_dof)
+    h = 1e-9 * np.abs(U).max()
+    Fp = ctx.step(U + h * v, Ep, want=('F', 'ind_p'))
+    Fm = ctx.step(U - h * v, Ep, want=('F', 'ind_p'))
+    same = np.array_equal(Fp['ind_p'], r['ind_p']) and np.array_equal(Fm['ind_p'], r['ind_p'])
+    dF = (Fp['F'] - Fm['F']) / (2 * h)
+    Kv = r['K'] @ v
+    # points that change branch inside +-h contribute a kink; they are rare and bounded
+    tol = 1e-6 if same else 1e-3
+    assert np.abs(dF - Kv).max() <= tol * np.abs(Kv).max()
+    ctx.close()
+
+
 def test_gpu_ds_is_the_consistent_tangent_of_gpu_s(fep):
     """The kernel's `ds` against central differences of the kernel's own `s` (no oracle involved)."""
     rng = np.random.default_rng(3)
