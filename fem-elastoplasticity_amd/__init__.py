@@ -22,7 +22,7 @@ from ._lib import FepError, lib, lib_path
 from .build import build
 from .sharding import Partition, ShardedContext, element_ranges
 from .newton import solve_strip_footing, solve_tsx_tunnel, transform
-from .solver import KrylovSolver
+from .solver import KrylovSolver, build_amg_hierarchy
 from .midpoints import create_midpoints, create_midpoints_P2, create_midpoints_P4
 from . import plasticity2d_dp, tsx_tunnel, elasticity2d
 
@@ -30,6 +30,6 @@ __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get
            'element_tables', 'assemble_mesh', 'square_mesh', 'rect_mesh', 'Partition', 'ShardedContext', 'element_ranges', 'MeshContext', 'construct_constitutive_problem',
            'construct_constitutive_problem_tsx', 'get_elastic_stiffness_matrix', 'get_elastic_stiffness_matrix_el',
            'assemble_tangent', 'default_device', 'FepError', 'lib', 'lib_path', 'build',
-           'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'KrylovSolver', 'create_midpoints', 'create_midpoints_P2',
+           'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'KrylovSolver', 'build_amg_hierarchy', 'create_midpoints', 'create_midpoints_P2',
            'create_midpoints_P4',
            'plasticity2d_dp', 'tsx_tunnel', 'elasticity2d']

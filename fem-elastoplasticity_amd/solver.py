@@ -100,6 +100,46 @@ def _stream(torch, device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=200, max_levels=8):
+    """Smoothed-aggregation hierarchy of Q K Q + (I - Q) (host, SciPy).  Returns one dict per transfer k -> k+1:
+    'P' (n_k x n_{k+1}), 'R' = P^T, 'A' = operator of level k+1 (its dense INVERSE in CSR form when 'last'),
+    'D' = inverse of A's 3x3 block diagonal (None when 'last'), 'omega' = Jacobi damping on level k, 'size' =
+    (DOFs, nnz) of the level-(k+1) operator — exactly what fep_solver_amg_push_level takes."""
+    f = np.asarray(free_dof, dtype=bool).ravel().astype(np.float64)
+    Dq = ssp.diags(f)
+    A = (Dq @ K @ Dq + ssp.diags(1.0 - f)).tocsr()
+    xy = np.asarray(coordinates, dtype=np.float64)
+    bs, out = 2, []
+    Di = _block_diag_inverse(A, bs)
+    rho = _rho(A, Di)
+    for level in range(max_levels):
+        agg, na = _aggregate(A, bs)
+        Pt, cxy = _tentative(agg, na, xy, bs)
+        if bs == 2:
+            Pt = (Dq @ Pt).tocsr()                       # constrained DOFs neither interpolate nor receive
+        P = (Pt - (4.0 / (3.0 * rho)) * (Di @ (A @ Pt))).tocsr()
+        Ac = (P.T @ A @ P).tocsr()
+        Ac.sum_duplicates()
+        last = na <= coarse_nodes or level == max_levels - 1 or 3 * na > 0.7 * A.shape[0]
+        R = P.T.tocsr()
+        if last:
+            dense = Ac.toarray()
+            dense += 1e-10 * np.abs(dense).max() * np.eye(dense.shape[0])
+            Aop, Dc = ssp.csr_matrix(np.linalg.inv(dense)), None
+        else:
+            Aop, Dc = Ac, _block_diag_inverse(Ac, 3)
+        for M in (P, R, Aop, Dc):
+            if M is not None:
+                M.sort_indices()
+        out.append({'P': P, 'R': R, 'A': Aop, 'D': Dc, 'omega': 4.0 / (3.0 * 1.05 * rho), 'last': last,
+                    'size': (Ac.shape[0], Ac.nnz)})
+        if last:
+            break
+        A, xy, bs, Di = Ac, cxy, 3, Dc
+        rho = _rho(A, Di)
+    return out
+
+
 class KrylovSolver:
     """PCG on the free DOFs `free_dof` (bool, DOF order = Q.flatten(order='F')) of the pattern of `ctx`
     (a MeshContext) or of an explicit `(indptr, indices)` pair with `device`."""
@@ -158,49 +198,21 @@ class KrylovSolver:
         ip, ix = self._pattern
         data = K_ref.data if hasattr(K_ref, 'indptr') else np.asarray(K_ref, dtype=np.float64)
         K = ssp.csr_matrix((data, ix, ip), shape=(self.n_dof, self.n_dof))
-        f = self.free_dof.astype(np.float64)
-        Dq = ssp.diags(f)
-        A = (Dq @ K @ Dq + ssp.diags(1.0 - f)).tocsr()
-        xy = np.asarray(coordinates, dtype=np.float64)
+        levels = build_amg_hierarchy(K, self.free_dof, coordinates, coarse_nodes, max_levels)
         l = _lib.lib()
         _lib.check(l.fep_solver_amg_clear(self._h), 'fep_solver_amg_clear')
-        bs, sizes = 2, [(A.shape[0], A.nnz)]
-        Di = _block_diag_inverse(A, bs)
-        rho = _rho(A, Di)
-        for level in range(max_levels):
-            agg, na = _aggregate(A, bs)
-            Pt, cxy = _tentative(agg, na, xy, bs)
-            if bs == 2:
-                Pt = (Dq @ Pt).tocsr()
-            P = (Pt - (4.0 / (3.0 * rho)) * (Di @ (A @ Pt))).tocsr()
-            Ac = (P.T @ A @ P).tocsr()
-            Ac.sum_duplicates()
-            last = na <= coarse_nodes or level == max_levels - 1 or 3 * na > 0.7 * A.shape[0]
-            omega = 4.0 / (3.0 * 1.05 * rho)
-            R = P.T.tocsr()
-            if last:
-                dense = Ac.toarray()
-                dense += 1e-10 * np.abs(dense).max() * np.eye(dense.shape[0])
-                Aop, Dc = ssp.csr_matrix(np.linalg.inv(dense)), None
-            else:
-                Aop, Dc = Ac, _block_diag_inverse(Ac, 3)
+        for lv in levels:
             mats = []
-            for M in (P, R, Aop, Dc):
+            for M in (lv['P'], lv['R'], lv['A'], lv['D']):
                 if M is None:
                     mats += [None, None, None]
                 else:
-                    M.sort_indices()
                     mats += [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
                              np.ascontiguousarray(M.data, dtype=np.float64)]
-            _lib.check(l.fep_solver_amg_push_level(self._h, P.shape[0], P.shape[1], *[_lib.ptr(m) for m in mats],
-                                                   float(omega), int(last)), 'fep_solver_amg_push_level')
-            sizes.append((Ac.shape[0], Ac.nnz))
-            if last:
-                break
-            A, xy, bs, Di = Ac, cxy, 3, Dc
-            rho = _rho(A, Di)
-        self.amg_levels = sizes
-        return sizes
+            _lib.check(l.fep_solver_amg_push_level(self._h, lv['P'].shape[0], lv['P'].shape[1], *[_lib.ptr(m) for m in mats],
+                                                   float(lv['omega']), int(lv['last'])), 'fep_solver_amg_push_level')
+        self.amg_levels = [(K.shape[0], K.nnz)] + [lv['size'] for lv in levels]
+        return self.amg_levels
 
     def spmv(self, k_data, x, out=None, masked=False):
         """y = K x (masked: rows of constrained DOFs zeroed; x must be 0 there).  Device tensors in and out."""

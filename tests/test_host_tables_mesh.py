@@ -78,3 +78,64 @@ def test_midpoints_structured_matches_p2_generator_geometry(fep):
     for s, (a, b) in enumerate(((1, 2), (2, 0), (0, 1))):
         assert np.array_equal(co[:, el[3 + s]], (co[:, el[a]] + co[:, el[b]]) / 2)
     assert co.shape[1] == 36 + 85                                                # nodes + edges of a 5x5 cell square
+
+
+def test_multigrid_hierarchy_on_the_host(fep):
+    """solver.build_amg_hierarchy is host code (SciPy + fep_aggregate_host): structure of what gets pushed to the GPU,
+    and a SciPy replica of the device V(2,2) cycle as preconditioner of CG on an elastic K from the CPU checker."""
+    import scipy.sparse as ssp
+    from oracle import fep_oracle as orc
+    from conftest import dp_materials
+    mesh = fep.square_mesh(40, 'P1', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    d1, d2, wf = fep.element_tables('P1')
+    sh, bu, eta, c = dp_materials(elem.shape[1])
+    K = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)[0].tocsr()
+    qf = mesh['Q'].flatten(order='F')
+    lv = fep.build_amg_hierarchy(K, qf, coord, coarse_nodes=40)
+    assert len(lv) >= 2 and lv[-1]['last'] and not any(l['last'] for l in lv[:-1])
+    n = K.shape[0]
+    f = qf.astype(float)
+    A0 = (ssp.diags(f) @ K @ ssp.diags(f) + ssp.diags(1 - f)).tocsr()
+    ops = [A0]
+    for k, l in enumerate(lv):
+        P, R = l['P'], l['R']
+        assert P.shape[0] == (n if k == 0 else lv[k - 1]['P'].shape[1]) and P.shape[1] % 3 == 0
+        assert abs(R - P.T).max() == 0.0
+        Ac = (P.T @ ops[-1] @ P).tocsr()
+        if l['last']:
+            assert l['D'] is None
+            v = Ac @ np.random.default_rng(1).normal(size=Ac.shape[0])       # in the range (aggregates of constrained
+            assert np.abs(Ac @ (l['A'] @ v) - v).max() <= 1e-5 * np.abs(v).max()  # nodes leave empty rows: regularised)
+        else:
+            assert abs(l['A'] - Ac).max() <= 1e-9 * abs(Ac).max() and abs(Ac - Ac.T).max() <= 1e-9 * abs(Ac).max()
+            assert l['D'].shape == Ac.shape
+        assert 0.2 < l['omega'] < 1.0
+        ops.append(Ac)
+    assert abs(lv[0]['P'][~qf]).sum() == 0.0                       # constrained DOFs take no correction
+
+    def block_jacobi_inverse(A):
+        from importlib import import_module
+        return import_module('fem-elastoplasticity_amd.solver')._block_diag_inverse(A, 2)
+
+    D0 = block_jacobi_inverse(A0)
+
+    def vcycle(k, b):                                              # mirrors fep_solver.hip `vcycle`
+        if k == len(lv):
+            return lv[-1]['A'] @ b
+        A, D, w = (A0, D0, lv[0]['omega']) if k == 0 else (lv[k - 1]['A'], lv[k - 1]['D'], lv[k]['omega'])
+        x = w * (D @ b)
+        x = x + w * (D @ (b - A @ x))
+        x = x + lv[k]['P'] @ vcycle(k + 1, lv[k]['R'] @ (b - A @ x))
+        for _ in range(2):
+            x = x + w * (D @ (b - A @ x))
+        return x
+
+    b = np.random.default_rng(0).normal(size=n) * f
+    x = np.zeros(n); r = b.copy(); z = vcycle(0, r); p = z.copy(); rz = r @ z
+    for it in range(1, 200):
+        Ap = A0 @ p; a = rz / (p @ Ap); x += a * p; r -= a * Ap
+        if np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b):
+            break
+        z = vcycle(0, r); rz2 = r @ z; p = z + (rz2 / rz) * p; rz = rz2
+    assert it < 80 and np.linalg.norm(A0 @ x - b) <= 1e-9 * np.linalg.norm(b)
