@@ -14,7 +14,7 @@ Flavours of the reference's three `pythonFEM.py` copies:
 """
 from .tables import (ELEMENT_SHAPE, LagrangeElementType, element_tables, get_local_basis_volume,
                      get_quadrature_volume)
-from .mesh import assemble_mesh, rect_mesh, square_mesh
+from .mesh import assemble_mesh, rect_mesh, renumber_for_locality, square_mesh
 from .hotpath import (MeshContext, assemble_tangent, construct_constitutive_problem,
                       construct_constitutive_problem_tsx, default_device, get_elastic_stiffness_matrix,
                       get_elastic_stiffness_matrix_el)
@@ -27,7 +27,7 @@ from .midpoints import create_midpoints, create_midpoints_P2, create_midpoints_P
 from . import plasticity2d_dp, tsx_tunnel, elasticity2d
 
 __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get_local_basis_volume',
-           'element_tables', 'assemble_mesh', 'square_mesh', 'rect_mesh', 'Partition', 'ShardedContext', 'element_ranges', 'MeshContext', 'construct_constitutive_problem',
+           'element_tables', 'assemble_mesh', 'square_mesh', 'rect_mesh', 'renumber_for_locality', 'Partition', 'ShardedContext', 'element_ranges', 'MeshContext', 'construct_constitutive_problem',
            'construct_constitutive_problem_tsx', 'get_elastic_stiffness_matrix', 'get_elastic_stiffness_matrix_el',
            'assemble_tangent', 'default_device', 'FepError', 'lib', 'lib_path', 'build',
            'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'KrylovSolver', 'build_amg_hierarchy', 'create_midpoints', 'create_midpoints_P2',

@@ -128,3 +128,35 @@ def _square(N, t, size_xy):
 def assemble_mesh(level, element_type, size_xy):
     """Reference signature (DP:354-361): N_x = size_xy * 2**level cells per side (DP:67)."""
     return square_mesh(size_xy * 2 ** level, element_type, size_xy)
+
+
+def renumber_for_locality(elements, coordinates):
+    """Node and element numbering along a Morton (Z-order) curve — no counterpart in the reference, whose meshes come
+    numbered row by row.  The GPU path gathers node and element data of neighbouring nodes together; a mesh numbered
+    at random runs ~7x slower, this restores locality.
+
+    Returns (elements2, coordinates2, node_perm, elem_perm) with coordinates2 = coordinates[:, node_perm],
+    elements2 = inverse(node_perm)[elements[:, elem_perm]]: new node i is old node node_perm[i], new element j is old
+    element elem_perm[j].  Nodal results map back with  old[:, node_perm] = new,  point results (n_q per element) with
+    old.reshape(rows, n_e, n_q)[:, elem_perm] = new.reshape(rows, n_e, n_q)."""
+    elements = np.asarray(elements)
+    coordinates = np.asarray(coordinates, dtype=float)
+
+    def spread(v):
+        v = v.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+        for s, m in ((16, 0x0000FFFF0000FFFF), (8, 0x00FF00FF00FF00FF), (4, 0x0F0F0F0F0F0F0F0F),
+                     (2, 0x3333333333333333), (1, 0x5555555555555555)):
+            v = (v | (v << np.uint64(s))) & np.uint64(m)
+        return v
+
+    def morton(xy):
+        lo, hi = xy.min(axis=1, keepdims=True), xy.max(axis=1, keepdims=True)
+        q = np.floor((xy - lo) / np.where(hi > lo, hi - lo, 1.0) * 65535.0).astype(np.int64)
+        return spread(q[0]) | (spread(q[1]) << np.uint64(1))
+
+    node_perm = np.argsort(morton(coordinates), kind='stable')
+    inv = np.empty_like(node_perm)
+    inv[node_perm] = np.arange(node_perm.size)
+    centroids = coordinates[:, elements].mean(axis=1)
+    elem_perm = np.argsort(morton(centroids), kind='stable')
+    return inv[elements[:, elem_perm]], coordinates[:, node_perm], node_perm, elem_perm

@@ -139,3 +139,27 @@ def test_multigrid_hierarchy_on_the_host(fep):
             break
         z = vcycle(0, r); rz2 = r @ z; p = z + (rz2 / rz) * p; rz = rz2
     assert it < 80 and np.linalg.norm(A0 @ x - b) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_renumber_for_locality_is_a_consistent_permutation(fep):
+    from oracle import fep_oracle as orc
+    from conftest import dp_materials
+    rng = np.random.default_rng(2)
+    mesh = fep.square_mesh(10, 'P2', 10)
+    n_n = mesh['coordinates'].shape[1]
+    pn, pe = rng.permutation(n_n), rng.permutation(mesh['elements'].shape[1])
+    inv = np.empty(n_n, dtype=np.int64); inv[pn] = np.arange(n_n)
+    coord, elem = mesh['coordinates'][:, pn], inv[mesh['elements'][:, pe]]              # a badly numbered mesh
+    e2, c2, node_perm, elem_perm = fep.renumber_for_locality(elem, coord)
+    assert sorted(node_perm) == list(range(n_n)) and sorted(elem_perm) == list(range(elem.shape[1]))
+    assert np.array_equal(c2, coord[:, node_perm]) and np.array_equal(node_perm[e2], elem[:, elem_perm])
+    # locality: consecutive new nodes are close, consecutive new elements share nodes far more often than before
+    d_new = np.abs(np.diff(c2, axis=1)).sum(axis=0).mean(); d_old = np.abs(np.diff(coord, axis=1)).sum(axis=0).mean()
+    assert d_new < 0.25 * d_old
+    # same physics: K of the renumbered mesh is the permuted K
+    d1, d2, wf = fep.element_tables('P2')
+    sh, bu, eta, c = dp_materials(elem.shape[1] * 7)
+    K1 = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)[0].tocsr()
+    K2 = orc.elastic_setup(e2, c2, sh, bu, d1, d2, wf)[0].tocsr()
+    dof = (2 * node_perm[:, None] + np.arange(2)[None, :]).ravel()
+    assert abs(K1[dof][:, dof] - K2).max() <= 1e-9 * abs(K1).max()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Hot path on an UNSTRUCTURED P1 mesh (Delaunay triangulation of jittered points): which route the context picks,
 tile statistics and step time, for different node / element numberings.
-    python tools/unstructured_bench.py [n_points_per_side=708] [order=morton|random|rows]"""
+    python tools/unstructured_bench.py [n_points_per_side=708] [order=morton|random|rows] [renumber]"""
 import importlib
 import os
 import sys
@@ -50,6 +50,8 @@ if order == 'random':
 else:                                                   # elements follow their lowest node (what a mesher that numbers nodes first does)
     eperm = np.argsort(tri.min(axis=0), kind='stable')
 tri = tri[:, eperm]
+if len(sys.argv) > 3 and sys.argv[3] == 'renumber':          # what a caller with a badly numbered mesh should do first
+    tri, pts, _, _ = fep.renumber_for_locality(tri, pts)
 t_mesh = time.time() - t0
 t0 = time.time()
 ctx = fep.MeshContext(tri, pts)
