@@ -911,6 +911,7 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
                             double* ep_prev_d, int accept, double* e_out_d, double* s_d, double* ds_d,
                             uint8_t* ind_p_d, double* k_data_d, double* f_out_d, int64_t* counts_d) {
     if (!c || !u_d) return FEP_EINVAL;
+    if (!fep_aligned16(u_d) || !fep_aligned16(f_out_d) || !fep_aligned16(k_data_d)) return FEP_EINVAL;
     if (!c->have_materials) return FEP_ESTATE;
     FEP_TRY(fep_set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -971,6 +972,7 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
                                 double* k_data_d, double* f_out_d) {
     if (!c) return FEP_EINVAL;
     if ((k_data_d && !ds_d) || (f_out_d && !s_d)) return FEP_EINVAL;
+    if (!fep_aligned16(f_out_d) || !fep_aligned16(k_data_d)) return FEP_EINVAL;
     FEP_TRY(fep_set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (c->p1_node) {

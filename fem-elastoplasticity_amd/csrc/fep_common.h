@@ -21,4 +21,7 @@ extern __attribute__((visibility("hidden"))) thread_local int fep_g_last_hip;   
         if (_r != FEP_OK) return _r;   \
     } while (0)
 
-__attribute__((visibility("hidden"))) int fep_set_device(int dev);              // hipSetDevice with range check -> FEP_ENODEV
+__attribute__((visibility("hidden"))) int fep_set_device(int dev);
+
+#include <stdint.h>
+static inline bool fep_aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }   // NULL counts as aligned              // hipSetDevice with range check -> FEP_ENODEV

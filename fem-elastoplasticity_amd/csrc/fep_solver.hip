@@ -510,6 +510,7 @@ extern "C" int fep_solver_sizes(const fep_solver* s, int64_t sizes[4]) {
 extern "C" int fep_solver_spmv_dev(fep_solver* s, void* stream, const double* k_data_d, const double* x_d,
                                    double* y_d, int masked) {
     if (!s || !k_data_d || !x_d || !y_d || x_d == y_d) return FEP_EINVAL;
+    if (!fep_aligned16(k_data_d) || !fep_aligned16(x_d) || !fep_aligned16(y_d)) return FEP_EINVAL;
     FEP_TRY(fep_set_device(s->device));
     hipStream_t st = (hipStream_t)stream;
     if (masked)
@@ -526,6 +527,7 @@ extern "C" int fep_solver_pcg_dev(fep_solver* s, void* stream, const double* k_d
                                   double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
                                   int* state_out) {
     if (!s || !k_data_d || !b_d || !x_d || !(rtol >= 0.0) || max_iter < 0) return FEP_EINVAL;
+    if (!fep_aligned16(k_data_d) || !fep_aligned16(b_d) || !fep_aligned16(x_d)) return FEP_EINVAL;
     if (check_every <= 0) check_every = 50;
     FEP_TRY(fep_set_device(s->device));
     hipStream_t st = (hipStream_t)stream;
@@ -691,6 +693,7 @@ extern "C" int fep_solver_amg_pcg_dev(fep_solver* s, void* stream, const double*
                                       double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
                                       int* state_out) {
     if (!s || !k_data_d || !b_d || !x_d || !(rtol >= 0.0) || max_iter < 0) return FEP_EINVAL;
+    if (!fep_aligned16(k_data_d) || !fep_aligned16(b_d) || !fep_aligned16(x_d)) return FEP_EINVAL;
     if (s->levels.empty() || !s->levels.back().last) return FEP_ESTATE;
     if (check_every <= 0) check_every = 10;
     FEP_TRY(fep_set_device(s->device));

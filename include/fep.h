@@ -20,6 +20,9 @@
  *   - `ds` holds the 3x3 consistent tangent row-major, m = 3*i + j            DP:703
  *   - pointers named *_h are host memory, *_d are device (HBM) memory of the
  *     context's GPU; the caller owns every pointer for the duration of the call;
+ *   - device vectors indexed by DOF or by CSR position (U, F, k_data, the solver's x, b, y) must be 16-byte
+ *     aligned (hipMalloc and every tensor library deliver that; checked, FEP_EINVAL otherwise): the kernels move
+ *     them as (x, y) pairs;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); *_dev
  *     calls only enqueue work and return, *_host calls are synchronous;
  *   - calls on one context are not re-entrant; one context per (host thread, GPU).

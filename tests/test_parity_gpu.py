@@ -400,6 +400,26 @@ def test_full_size_p1_properties(fep):
     ctx.close()
 
 
+def test_misaligned_device_vectors_are_refused(fep):
+    """The kernels move U, F and the CSR values as 16-byte pairs: an odd-double offset must come back as an error code,
+    never reach a kernel."""
+    import torch
+    mesh = fep.square_mesh(8, 'P1', 10)
+    ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
+    ctx.set_materials(*[v[0] for v in dp_materials(1)])
+    dev = torch.device('cuda', 0)
+    buf = torch.zeros(ctx.n_dof + 2, dtype=torch.float64, device=dev)
+    F = torch.zeros(ctx.n_dof + 2, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.step_dev(st, buf.data_ptr(), f_out=F.data_ptr())                                   # aligned: fine
+    with pytest.raises(fep.FepError, match='invalid argument'):
+        ctx.step_dev(st, buf.data_ptr() + 8, f_out=F.data_ptr())
+    with pytest.raises(fep.FepError, match='invalid argument'):
+        ctx.step_dev(st, buf.data_ptr(), f_out=F.data_ptr() + 8)
+    torch.cuda.synchronize()
+    ctx.close()
+
+
 def test_error_codes(fep):
     elem = np.array([[0], [1], [5]])                      # node id out of range
     coord = np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
