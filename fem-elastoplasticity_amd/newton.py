@@ -13,6 +13,8 @@ The linear solve (the reference's dense `np.linalg.solve` on a (2 n_n)^2 boolean
   linear_solver='pcg'     conjugate gradients on the GPU (solver.py, block-Jacobi preconditioner); the iterate, K, F,
                           the plastic strain and the stopping norms then never leave the device, or
   linear_solver='amg'     the same with the smoothed-aggregation multigrid preconditioner built once from K_elast.
+`pcg_forcing` (e.g. 1e-2) makes the Newton iteration inexact: the linear tolerance follows the previous iterate's
+stopping quantity instead of being 1e-11 throughout; the converged states are the same to the Newton tolerance.
 `transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is re-stated
 with `np.bincount` on the host and as `fep_transform_dev` on the device.
 """
@@ -56,7 +58,7 @@ class _HostOps:
         kw = {} if e0 is None else {'e0': e0}
         return self.ctx.step(U, Ep, apply_plastic_strain=accept, want=want, **kw)
 
-    def solve(self, K, rhs):
+    def solve(self, K, rhs, criterion=None):
         rhs = np.asarray(rhs).ravel()
         x = np.zeros(rhs.size)
         x[self.qf] = sspl.spsolve(K[self.qf][:, self.qf].tocsc(), rhs[self.qf])
@@ -83,13 +85,13 @@ class _DeviceOps:
     `KrylovSolver.pcg` solves on them.  A linear solve that breaks down or runs out of iterations yields NaNs,
     which the drivers treat like the reference treats a NaN criterion (DP:1076): the load step is halved."""
 
-    def __init__(self, ctx, qf, rtol=1e-11, max_iter=200000):
+    def __init__(self, ctx, qf, rtol=1e-11, max_iter=200000, forcing=None):
         import torch
         from .solver import KrylovSolver
         self.torch, self.ctx, self.qf = torch, ctx, qf
         self.dev = torch.device('cuda', ctx.device)
         self.solver = KrylovSolver(ctx, qf)
-        self.rtol, self.max_iter = rtol, max_iter
+        self.rtol, self.max_iter, self.forcing = rtol, max_iter, forcing
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.kd = torch.empty(ctx.nnz, **f64)
         self.F = torch.empty(ctx.n_dof, **f64)
@@ -131,8 +133,14 @@ class _DeviceOps:
         # (1 M elements, 10 load steps: 6 rebuilds) and did not lower the iteration counts
         self.solver.setup_amg(self.host(K), coordinates)
 
-    def solve(self, K, rhs):
-        x = self.solver.pcg(K, rhs, rtol=self.rtol, max_iter=self.max_iter)
+    def solve(self, K, rhs, criterion=None):
+        # inexact Newton: while the iterate is far from converged the correction need not be solved to 11 digits.
+        # `criterion` is the stopping quantity of the previous Newton iterate (DP:1075); the linear residual is asked
+        # to be `forcing` times smaller than it, never looser than 1e-4 nor tighter than `rtol`.
+        rtol = self.rtol
+        if self.forcing and criterion is not None and np.isfinite(criterion):
+            rtol = min(1e-4, max(self.rtol, self.forcing * criterion))
+        x = self.solver.pcg(K, rhs, rtol=rtol, max_iter=self.max_iter)
         self.pcg_iters.append(self.solver.last['iters'])
         if self.solver.last['state'] != 1:
             x.fill_(float('nan'))
@@ -159,19 +167,19 @@ class _DeviceOps:
         self.solver.close()
 
 
-def _make_ops(ctx, qf, linear_solver, pcg_rtol):
+def _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing=None):
     if linear_solver == 'direct':
         return _HostOps(ctx, qf)
     if linear_solver in ('pcg', 'amg'):
         if not isinstance(ctx, MeshContext):
             raise ValueError(f"linear_solver='{linear_solver}' needs the GPU MeshContext")
-        return _DeviceOps(ctx, qf, rtol=pcg_rtol)
+        return _DeviceOps(ctx, qf, rtol=pcg_rtol, forcing=pcg_forcing)
     raise ValueError("linear_solver must be 'direct', 'pcg' or 'amg'")
 
 
 def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, max_steps=None, zeta_max=1.0,
                         device=None, log=None, context_factory=None, linear_solver='direct', pcg_rtol=1e-11,
-                        keep_U=True):
+                        keep_U=True, pcg_forcing=None):
     """Strip-footing benchmark of Plasticity2D_DP (DP:901-1131).  `level` as in the reference
     (N = size_xy * 2**level cells per side) or `n_cells` directly.  Returns a dict with the load history
     ('zeta', 'pressure'), the accepted displacements 'U' (list of (2,n_n)), final 'Ep', counters.
@@ -191,7 +199,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     ctx = (context_factory or (lambda *a: MeshContext(*a, device=device)))(elem, coord, d1, d2, wf)
     ctx.set_materials(shear0, bulk0, eta0, c_0)
     qf = Q.flatten(order='F')
-    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol)
+    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing)
     K_elast = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                        # DP:977
     if linear_solver == 'amg':
         ops.setup_amg(K_elast, coord)
@@ -216,7 +224,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
             r = ops.step(U_it, Ep_old, accept=False, want=('K', 'F'))                     # DP:1043-1058
             hist['n_calls'] += 1
             its += 1
-            dU = ops.solve(r['K'], -r['F'])                                               # DP:1062-1066
+            dU = ops.solve(r['K'], -r['F'], criterion if its > 1 else 1.0)                # DP:1062-1066
             U_new = U_it + dU
             q1, q2, q3 = ops.energy(K_elast, dU), ops.energy(K_elast, U_it), ops.energy(K_elast, U_new)   # DP:1072-1074
             criterion = q1 / (q2 + q3)
@@ -264,7 +272,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
 
 
 def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(0, 40), device=None, log=None,
-                     linear_solver='direct', pcg_rtol=1e-11):
+                     linear_solver='direct', pcg_rtol=1e-11, pcg_forcing=None):
     """TSX tunnel excavation (TSX:1637-1832) on a given mesh (`coords` (2,n_n), `elem` (n_p,n_e) 0-based; the
     reference reads coord.csv / elem.csv and, for P2/P4, adds midpoints first).  Returns the history of the
     monitored displacement, plastic-point counts and accepted displacements."""
@@ -290,7 +298,7 @@ def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(
     n_int = ctx.n_int
     assert n_int == elem.shape[1] * ELEMENT_SHAPE[t][1]
     ctx.set_materials(shear0, bulk0, eta0, c_0)
-    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol)
+    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing)
     K = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                              # TSX:1722
     if linear_solver == 'amg':
         ops.setup_amg(K, coords)
@@ -310,10 +318,10 @@ def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(
     while True:
         zeta = zeta_old + d_zeta
         e0 = zeta * init_strain                                                           # TSX:1765
-        for _ in range(25):
+        for it in range(25):
             r = ops.step(U_it, Ep_old, e0=e0, want=('K', 'F'))                            # TSX:1771-1778
             hist['n_calls'] += 1
-            dU = ops.solve(r['K'], -r['F'])                                               # TSX:1781
+            dU = ops.solve(r['K'], -r['F'], criterion if it > 0 else 1.0)                 # TSX:1781
             U_new = U_it + dU
             criterion = ops.energy(K, dU) / (ops.energy(K, U_it) + ops.energy(K, U_new))  # TSX:1788-1792
             if np.isnan(criterion):

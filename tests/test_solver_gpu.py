@@ -140,6 +140,22 @@ def test_drivers_with_multigrid_solver(fep):
         assert relerr(a['U'][k], b['U'][k]) <= 1e-9, k
 
 
+def test_inexact_newton_reaches_the_same_states_with_fewer_cg_iterations(fep):
+    a = fep.solve_strip_footing('P1', n_cells=48, max_steps=6)
+    b = fep.solve_strip_footing('P1', n_cells=48, max_steps=6, linear_solver='amg')
+    c = fep.solve_strip_footing('P1', n_cells=48, max_steps=6, linear_solver='amg', pcg_forcing=1e-2)
+    assert a['zeta'] == c['zeta'] and a['counts'] == c['counts']
+    for k in range(6):
+        assert relerr(a['U'][k], c['U'][k]) <= 1e-9, k
+    assert sum(c['pcg_iters']) < 0.8 * sum(b['pcg_iters'])
+    assert sum(c['newton_its']) <= sum(b['newton_its']) + 6            # at most one more Newton iterate per load step
+    g = __import__('conftest').load_golden('dp_p1_level1_trace')
+    h = fep.solve_strip_footing('P1', level=1, linear_solver='pcg', pcg_forcing=1e-2)
+    assert len(h['zeta']) == 16 and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
+    for k in range(16):
+        assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-9, k
+
+
 def test_solver_rejects_foreign_patterns(fep):
     ip = np.array([0, 2, 3, 5, 7], dtype=np.int32)                 # rows 0 and 1 of node 0 differ in length
     ix = np.array([0, 1, 0, 2, 3, 2, 3], dtype=np.int32)
