@@ -3,25 +3,33 @@
 Benchmark of the hot path: element*quadrature-point updates per second for
 strain -> Drucker-Prager return map -> tangent-stiffness (CSR values) -> internal force.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--cells C]
 
-Workload (BASELINE.json configs[3], the configuration the metric's target is quoted on): the
-strip-footing square refined to 708 x 708 cells = 1 002 528 P1 elements (= integration points) per
-GPU, Drucker-Prager materials of the reference demo (DP:910-933), a synthetic displacement field
-that puts points on all three branches (elastic / smooth / apex).  One step = one pass of the hot
-path with every input resident in HBM.  With N GPUs the mesh is a 708 x 708N rectangle sharded by
-contiguous element ranges (weak scaling); the only exchange is the RCCL all-reduce of the
-interface forces.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` as a
+CHILD process, before anything in this process touches the GPU), waits and returns the child's exit code; launched
+under torch.distributed.run (WORLD_SIZE set) it is one rank.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (fused element
-kernel, HIP-event timed on its stream, algorithmic bytes 537 B/update for P1: SURVEY 8d) and
-`cpu_baseline` (the NumPy oracle timed on this host, N=1 only).
+Workload (BASELINE.json configs[3], the configuration the metric's target is quoted on): the strip-footing
+square refined to 708 x 708 cells = 1 002 528 P1 elements (= integration points), Drucker-Prager materials of
+the reference demo (DP:910-933), a synthetic displacement field that puts points on all three branches
+(elastic / smooth / apex).  One step = one pass of the hot path with every input resident in HBM.
+  --scaling weak   (default) every GPU holds its own 708 x 708 square of a 708 x 708N rectangle;
+  --scaling strong ONE 708 x 708 square split N ways (configs[3] as written: "1 vs 2 vs 4 vs 8 GPUs").
+Either way the mesh is sharded by contiguous element ranges, the hot path has no data-path collective and the
+only exchange is the RCCL all-reduce of the interface forces (one node row per cut).  At N > 1 the weak line
+also carries a `strong` object: the same K steps on the one-square mesh split N ways.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event timed on the launch
+stream, algorithmic bytes 537 B/update for P1: SURVEY 8d) and `cpu_baseline` (the NumPy oracle timed on this
+host, N=1 only).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,10 +38,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_CELLS = 708                       # 2*708^2 = 1 002 528 P1 elements per GPU
+N_CELLS = 708                       # 2*708^2 = 1 002 528 P1 elements
 HBM_PEAK_GBS = 8000.0               # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s)
 ALG_BYTES = {'P1': 201 + 16 * 3 + 8 * 36 / 1, 'P2': 201 + 16 * 6 + 8 * 144 / 7,
-             'Q1': 201 + 16 * 4 + 8 * 64 / 4, 'Q2': 201 + 16 * 8 + 8 * 256 / 9}
+             'Q1': 201 + 16 * 4 + 8 * 64 / 4, 'Q2': 201 + 16 * 8 + 8 * 256 / 9,
+             'P4': 201 + 16 * 15 + 8 * 900 / 12}
 
 
 def dp_materials():
@@ -42,17 +51,18 @@ def dp_materials():
             3 * np.tan(phi) / np.sqrt(9 + 12 * np.tan(phi) ** 2), 3 * c0 / np.sqrt(9 + 12 * np.tan(phi) ** 2))
 
 
-def displacement(coord, seed=1):
-    """Synthetic state: shear/compression bands + noise, periodic in y with the strip height."""
+def displacement(coord, seed=1, scale=1.0):
+    """Synthetic state on the GLOBAL node set: shear/compression bands + noise, periodic in y with the strip
+    height.  `scale` multiplies the smooth part (scale 1: ~18 % smooth / 57 % apex points; see --field-scale)."""
     x, y = coord[0], np.mod(coord[1], 10.0)
-    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    U = scale * np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
     U += np.random.default_rng(seed).normal(0, 2e-8, size=U.shape)
     return U
 
 
-def cpu_baseline(fep, elem_type='P1', n_cells=354, repeats=3):
-    """The oracle (NumPy/SciPy restatement of the reference path) on a bounded sample of the same
-    workload: a quarter-size square with the same field and materials, 1 host thread."""
+def cpu_baseline(fep, elem_type='P1', n_cells=N_CELLS, repeats=3, scale=1.0):
+    """The oracle (NumPy/SciPy restatement of the reference path) on the same workload (same mesh, field and
+    materials), 1 host thread."""
     from oracle import fep_oracle as orc
     mesh = fep.square_mesh(n_cells, elem_type, 10)
     elem, coord = mesh['elements'], mesh['coordinates']
@@ -62,7 +72,7 @@ def cpu_baseline(fep, elem_type='P1', n_cells=354, repeats=3):
     one = np.ones(n_int)
     K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, G * one, Kb * one, d1, d2, wf)
     ctx = dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=G * one, bulk=Kb * one, eta=eta * one, c=c * one)
-    U = displacement(coord)
+    U = displacement(coord, scale=scale)
     Ep = np.zeros((4, n_int))
     best = float('inf')
     for _ in range(repeats):
@@ -70,28 +80,78 @@ def cpu_baseline(fep, elem_type='P1', n_cells=354, repeats=3):
         orc.hot_path(U, Ep, ctx)
         best = min(best, time.perf_counter() - t0)
     return {'value': n_int / best, 'unit': 'updates/s', 'cores': 1, 'kind': 'port',
-            'sample': f'oracle.hot_path (NumPy/SciPy, single thread) on a {n_cells}x{n_cells}-cell {elem_type} square '
+            'sample': f'oracle.hot_path (NumPy/SciPy, single thread) on the {n_cells}x{n_cells}-cell {elem_type} square '
                       f'({n_int} points, same field/materials), best of {repeats}, {best:.3f} s/pass; '
                       f'host has {os.cpu_count()} cores'}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--cells', type=int, default=N_CELLS, help='cells per side of the per-GPU square')
+    ap.add_argument('--cells', type=int, default=N_CELLS, help='cells per side of the square (per GPU when weak)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--field-scale', type=float, default=1.0,
+                    help='multiplies the displacement field (0.35: ~30 %% smooth, no apex points, like the Newton '
+                         'iterates of configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-cells', type=int, default=None, help='cells per side of the CPU-baseline square (default: --cells)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def launch_ranks(n):
+    """Fresh child process running torch.distributed.run with n ranks of this script; nothing in THIS process has
+    touched the GPU (torch is not even imported yet).  Returns the child's exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Shard:
+    """One rank's part of a mesh: device context + device-resident state of the benchmark step."""
+
+    def __init__(self, fep, torch, mesh, rank, world, dev, scale, two_buffers):
+        self.sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=dev.index)
+        ctx = self.ctx = self.sh.ctx
+        ctx.set_materials(*dp_materials())
+        n_int = self.n_int = ctx.n_int
+        # the field is a function of the GLOBAL node set (identical on every rank that shares a node)
+        U_h = displacement(mesh['coordinates'], scale=scale)[:, self.sh.nodes]
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.U = torch.from_numpy(np.ascontiguousarray(U_h.reshape(-1, order='F'))).to(dev)
+        self.Ep = torch.zeros((4, n_int), **f64)
+        self.S = torch.empty((4, n_int), **f64)
+        self.DS = torch.empty((9, n_int), **f64)
+        self.indp = torch.empty(n_int, dtype=torch.uint8, device=dev)
+        self.Kd = torch.empty(ctx.nnz, **f64)
+        self.Fb = [torch.empty(ctx.n_dof, **f64) for _ in range(2 if two_buffers else 1)]
+        self.counts = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def step(self, stream, i=0, full=True):
+        """full: every output of SURVEY 8d (s, ds, ind_p, K, F); else only what a Newton iterate reads (K, F)."""
+        self.ctx.step_dev(stream, self.U.data_ptr(), ep=self.Ep.data_ptr(), accept=False,
+                          s=self.S.data_ptr() if full else 0, ds=self.DS.data_ptr() if full else 0,
+                          ind_p=self.indp.data_ptr() if full else 0, k_data=self.Kd.data_ptr(),
+                          f_out=self.Fb[i].data_ptr(), counts=self.counts.data_ptr())
+
+
+def run(args):
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if os.environ.get('FEP_BENCH_SINGLE_DEVICE'):      # rehearsal of the N>1 path on a one-GPU box: every rank on GPU 0
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -102,85 +162,133 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     fep = importlib.import_module('fem-elastoplasticity_amd')
     fep.lib()                                      # fails loudly if the HIP extension is missing
     N = args.cells
-    mesh = fep.rect_mesh(N, N * world, 'P1', 10, 10 * world)
-    sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=local_rank)
-    ctx = sh.ctx
-    G, Kb, eta, c = dp_materials()
-    ctx.set_materials(G, Kb, eta, c)
-    n_int = ctx.n_int
-    U_h = displacement(mesh['coordinates'][:, sh.nodes])
     f64 = dict(dtype=torch.float64, device=dev)
-    U = torch.from_numpy(np.ascontiguousarray(U_h.reshape(-1, order='F'))).to(dev)
-    Ep = torch.zeros((4, n_int), **f64)
-    S = torch.empty((4, n_int), **f64)
-    DS = torch.empty((9, n_int), **f64)
-    indp = torch.empty(n_int, dtype=torch.uint8, device=dev)
-    Kd = torch.empty(ctx.nnz, **f64)
-    Fb = [torch.empty(ctx.n_dof, **f64) for _ in range(2 if world > 1 else 1)]
-    F = Fb[0]
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # N > 1: the interface all-reduce of pass i runs on a second stream under pass i+1's kernels (the force
-    # vector is double-buffered; a pass only waits for the exchange that last used its buffer)
     main = torch.cuda.current_stream()
+    stream = main.cuda_stream
     comm = torch.cuda.Stream() if world > 1 else None
-    ev_done = [torch.cuda.Event() for _ in range(2)]
-    ev_ready = [torch.cuda.Event() for _ in range(2)]
-    state = {'i': 0}
-
-    def step():
-        i = state['i'] & 1
-        state['i'] += 1
-        Fi = Fb[i] if world > 1 else F
-        if world > 1 and state['i'] > 2:
-            main.wait_event(ev_done[i])
-        ctx.step_dev(stream, U.data_ptr(), ep=Ep.data_ptr(), accept=False, s=S.data_ptr(), ds=DS.data_ptr(),
-                     ind_p=indp.data_ptr(), k_data=Kd.data_ptr(), f_out=Fi.data_ptr(), counts=counts.data_ptr())
-        if world > 1:
-            ev_ready[i].record(main)
-            comm.wait_event(ev_ready[i])
-            with torch.cuda.stream(comm):
-                sh.exchange_force_(Fi)
-                ev_done[i].record(comm)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], **f64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    n_smooth, n_apex = [int(v) for v in counts.cpu()]
+    def timed(shard, steps, warmup, full=True):
+        """warmup untimed + EXACTLY `steps` timed passes between barrier+synchronize; max over ranks.
+        N > 1: the interface all-reduce of pass i runs on a second stream under pass i+1's kernels (the force
+        vector is double-buffered; a pass only waits for the exchange that last used its buffer)."""
+        ev_done = [torch.cuda.Event() for _ in range(2)]
+        ev_ready = [torch.cuda.Event() for _ in range(2)]
+        state = {'i': 0}
 
-    # per-kernel durations IN SITU: the same step sequence again with HIP events around every kernel
-    # on the launch stream (not part of the timed region above)
-    ctx.profile_begin()
-    for _ in range(args.steps):
-        step()
-    kms, n_prof = ctx.profile_end(stream)
-    barrier()
+        def step():
+            i = state['i'] & 1 if world > 1 else 0
+            state['i'] += 1
+            if world > 1 and state['i'] > 2:
+                main.wait_event(ev_done[i])
+            shard.step(stream, i, full)
+            if world > 1:
+                ev_ready[i].record(main)
+                comm.wait_event(ev_ready[i])
+                with torch.cuda.stream(comm):
+                    shard.sh.exchange_force_(shard.Fb[i])
+                    ev_done[i].record(comm)
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], **f64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), step
+
+    def per_kernel(shard, step, steps):
+        """per-kernel durations IN SITU: the same step sequence again with HIP events around every kernel on the
+        launch stream (not part of the timed region)."""
+        shard.ctx.profile_begin()
+        for _ in range(steps):
+            step()
+        kms, n_prof = shard.ctx.profile_end(stream)
+        barrier()
+        return kms, n_prof
+
+    def exchange_ms(shard, reps=20):
+        if world == 1:
+            return None
+        with torch.cuda.stream(comm):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            shard.sh.exchange_force_(shard.Fb[0])
+            a.record(comm)
+            for _ in range(reps):
+                shard.sh.exchange_force_(shard.Fb[0])
+            b.record(comm)
+        barrier()
+        return a.elapsed_time(b) / reps
+
+    def gather_ranks(v):
+        t = torch.tensor(v, **f64)
+        if world == 1:
+            return [t.tolist()]
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.tolist() for o in out]
+
+    # ---- the headline run ------------------------------------------------------------------------------------
+    strong = args.scaling == 'strong'
+    mesh = fep.rect_mesh(N, N if strong else N * world, 'P1', 10, 10 if strong else 10 * world)
+    shard = Shard(fep, torch, mesh, rank, world, dev, args.field_scale, world > 1)
+    n_total = int(mesh['elements'].shape[1])
+    dt, step = timed(shard, args.steps, args.warmup)
+    cnt = shard.counts.clone()
+    if world > 1:
+        dist.all_reduce(cnt)
+    n_smooth, n_apex = [int(v) for v in cnt.cpu()]
+    kms, n_prof = per_kernel(shard, step, args.steps)
+    ranks_ms = gather_ranks([kms['element'], kms['csr'], kms['force']])
+    x_ms = exchange_ms(shard)
+    n_int = shard.n_int
+    ctx = shard.ctx
+
+    # K/F-only pass (what a Newton iterate asks for: no s / ds / ind_p leave the kernels), N = 1
+    kf = None
+    if world == 1:
+        dt_kf, step_kf = timed(shard, args.steps, args.warmup, full=False)
+        kms_kf, _ = per_kernel(shard, step_kf, args.steps)
+        kf = {'ms_per_step': dt_kf / args.steps * 1e3, 'updates_per_s': n_int * args.steps / dt_kf,
+              'kernels_ms': {'point': kms_kf['element'], 'assembly': kms_kf['csr'], 'force': kms_kf['force']},
+              'note': 'fep_step_dev with s = ds = ind_p = NULL (newton.py asks for K and F only)'}
+
+    # strong-scaling companion of a weak run (N > 1): ONE N x N square split over the ranks
+    strong_line = None
+    if world > 1 and not strong:
+        mesh_s = fep.rect_mesh(N, N, 'P1', 10, 10)
+        shard_s = Shard(fep, torch, mesh_s, rank, world, dev, args.field_scale, True)
+        dt_s, step_s = timed(shard_s, args.steps, args.warmup)
+        kms_s, _ = per_kernel(shard_s, step_s, args.steps)
+        rk = gather_ranks([kms_s['element'], kms_s['csr'], float(shard_s.n_int)])
+        n_s = int(mesh_s['elements'].shape[1])
+        strong_line = {'value': n_s * args.steps / dt_s, 'unit': 'updates/s', 'ms_per_step': dt_s / args.steps * 1e3,
+                       'elements_total': n_s, 'scaling': 'strong',
+                       'per_rank': [{'elements': int(r[2]), 'point_ms': r[0], 'assembly_ms': r[1]} for r in rk],
+                       'exchange_ms': exchange_ms(shard_s)}
+        shard_s.sh.close()
+
     route = os.environ.get('FEP_P1_PATH', '') or 'node'
     if route == 'coo':
         # fused element kernel: strain + return map + K_e/f_e blocks (exactly the work SURVEY 8d prices)
         k_ms = kms['element']
         k_name = 'element_kernel<3,1,true> (strain + return map + K_e/f_e)'
         others = {'csr_reduce_kernel': kms['csr'], 'force_reduce_kernel': kms['force']}
-        per_kernel = None
+        per_k = None
     else:
         # node route: the priced work (return map + tangent assembly) is the PAIR of kernels; the
         # figure divides SURVEY 8d's bytes by the SUM of both durations (which also includes the CSR
@@ -194,45 +302,70 @@ def main():
         # assembly = ds 48 (6 of 9 rows) + s 24 + geometry record 48 + descriptors/codes 32 + CSR values 8*nnz/n + force 16*n_n/n
         b_point = 181.0 * n_int
         b_node = (48 + 24 + 48 + 32) * n_int + 8.0 * ctx.nnz + 8.0 * ctx.n_dof
-        per_kernel = {'p1_point_kernel': {'bytes': b_point, 'GBps': b_point / (kms['element'] * 1e-3) / 1e9,
-                                          'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                      'p1_node_kernel': {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
-                                         'frac': b_node / (kms['csr'] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        per_k = {'p1_point_kernel': {'bytes': b_point, 'GBps': b_point / (kms['element'] * 1e-3) / 1e9,
+                                     'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                 'p1_node_kernel': {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
+                                    'frac': b_node / (kms['csr'] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     alg = ALG_BYTES['P1'] * n_int
     achieved = alg / (k_ms * 1e-3) / 1e9
 
     if rank == 0:
-        traffic = None
+        # HBM traffic is NOT measured by this run (PMC counters need their own rocprofv3 passes): the figure is the
+        # one recorded by tools/summarize_profile.py from the committed counter passes of the same command
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('elements_per_gpu', 1002528) == n_int and route == 'node':
+                if tj.get('elements_per_gpu', 1002528) == n_int and route == 'node' and args.field_scale == 1.0:
                     traffic = tj.get('hbm_bytes_per_launch')
+                    traffic_source = ('profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                      '`python bench.py`, 2*FETCH + WRITE per the gfx950 correction; not measured in this run)')
             except Exception:
                 traffic = None
+        label = ' (BASELINE configs[3])' if N == N_CELLS else ''
+        if strong:
+            wl = (f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_total} P1 elements{label} split over '
+                  f'{world} GPU(s)')
+        else:
+            wl = (f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_int} P1 elements per GPU{label}')
         line = {
             'metric': 'element*quadpt updates/sec (return-map + K_tan assemble)',
-            'value': world * n_int * args.steps / dt, 'unit': 'updates/s',
+            'value': n_total * args.steps / dt, 'unit': 'updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_int} P1 elements per GPU '
-                                   f'(BASELINE configs[3]), Drucker-Prager, strain->return map->K_tan CSR values->F per step',
-                       'elements_per_gpu': n_int, 'nnz_per_gpu': ctx.nnz, 'smooth_points': n_smooth, 'apex_points': n_apex,
+            'config': {'workload': wl + ', Drucker-Prager, strain->return map->K_tan CSR values->F per step',
+                       'elements_per_gpu': n_int, 'elements_total': n_total, 'nnz_per_gpu': ctx.nnz,
+                       'smooth_points': n_smooth, 'apex_points': n_apex, 'field_scale': args.field_scale,
                        'route': route,
                        'parallelism': f'element-shard x{world}, interface-force all-reduce' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': k_name, 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_launch': alg, 'timing': f'HIP events in situ, mean of {n_prof} launches',
-                         'kernels_ms': others, 'per_kernel': per_kernel},
+                         'kernels_ms': others, 'per_kernel': per_k},
         }
+        if world > 1:
+            line['per_rank'] = [{'point_ms': r[0], 'assembly_ms': r[1]} for r in ranks_ms]
+            line['exchange_ms'] = x_ms
+            if strong_line:
+                line['strong'] = strong_line
+        if kf:
+            line['kf_only'] = kf
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(fep)
+            line['cpu_baseline'] = cpu_baseline(fep, n_cells=args.cpu_cells or N, scale=args.field_scale)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    run(args)
 
 
 if __name__ == '__main__':

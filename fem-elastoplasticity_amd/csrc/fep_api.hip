@@ -1,6 +1,7 @@
 // C-ABI implementation of include/fep.h (libfep_hip.so).  Host side: context, symbolic
 // phase (node graph -> CSR pattern + gather lists), launches.  Device side: fep_kernels.hip.h.
 #include "fep_common.h"
+#include "fep_host.h"
 #include "fep_kernels.hip.h"
 
 #include <algorithm>
@@ -39,9 +40,18 @@ struct fep_ctx {
     int32_t *wg_eptr = nullptr, *wg_elist = nullptr, *wg_rng = nullptr;   // wg_rng: <= 8 (start, cum) runs per tile
     bool p1_rng = false, p1_pk = false;
     uint2* pk = nullptr;                                // packed block descriptors, lanes sorted by segment length
-    int2* tile_fnode0 = nullptr;                        // (first node, number of nodes) per tile
-    int32_t* tstart = nullptr;  // tstart: first block of every tile (tiles hold whole nodes)
+    int4* tdesc = nullptr;                              // P1 tiles: (1 + kSegMax) int4 per tile (fep_host.h, P1Plan)
+    int p1_segs = 1;                                    // segments per tile of the plan in use
+    int32_t* tstart = nullptr;                          // COO route: first block of every tile of csr_reduce_kernel
     int n_wg_p1 = 0;   // LDS-staged variant: per-workgroup element lists
+    // one-kernel step (p1_fused_kernel): per-tile node lists / runs, per staged element its tile-local node indices + owner bit
+    bool p1_fused = false, p1_fused_rng = false;
+    int fused_mode = 2;                                 // FEP_P1_FUSED: 0 = never, 1 = only when no point output is wanted, 2 = always
+    int lds_NL = 0;                                     // staged nodes per tile (max)
+    int32_t *wg_nlist = nullptr, *wg_nrng = nullptr;
+    uint32_t* el_nodes = nullptr;
+    unsigned long long* slot_counts = nullptr;          // 256 slots x 16 words, zero between steps
+    bool has_orphans = false;                           // nodes that belong to no element (their F entries are zeroed per step)
     uint16_t* perm_l = nullptr;
     int tile = 256;                                     // node-pair blocks per workgroup of the assembly kernel
     bool gn = false;                                    // node route for P2 / Q1 / Q2 (point_kernel + node_lds_kernel)
@@ -233,104 +243,10 @@ extern "C" int fep_return_map_host(int device_id, int64_t n_int,
     return FEP_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// Symbolic phase (host).  Node graph of the mesh -> (i) CSR pattern of K on DOFs,
-// (ii) per node-pair block the list of element-local blocks that sum into it,
-// (iii) per node the list of (element, local node) pairs for the force gather.
-// ---------------------------------------------------------------------------------------
-struct Symbolic {
-    std::vector<int32_t> iptr, ilist;        // node -> incident (a*n_e + e), ordered by (e, a)
-    std::vector<int32_t> nptr, ncol;         // node CSR (sorted neighbour nodes)
-    std::vector<int32_t> segptr, perm;       // block -> contributions (a*NP+b)*n_e + e
-    std::vector<uint32_t> meta;              // block -> (deg << 16) | slot
-};
+using fep_host::Symbolic;
+using fep_host::build_symbolic;
 
-
-static int build_symbolic(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem, Symbolic& S) {
-    if ((int64_t)n_p * n_p * n_e >= (int64_t)INT32_MAX / 2) return FEP_ERANGE;
-    for (int64_t i = 0; i < (int64_t)n_p * n_e; ++i)
-        if (elem[i] < 0 || elem[i] >= n_n) return FEP_ERANGE;
-    // (iii) incidence lists
-    S.iptr.assign(n_n + 1, 0);
-    for (int64_t i = 0; i < (int64_t)n_p * n_e; ++i) S.iptr[elem[i] + 1]++;
-    for (int64_t n = 0; n < n_n; ++n) S.iptr[n + 1] += S.iptr[n];
-    S.ilist.resize(S.iptr[n_n]);
-    {
-        std::vector<int32_t> fill(S.iptr.begin(), S.iptr.end() - 1);
-        for (int64_t e = 0; e < n_e; ++e)
-            for (int a = 0; a < n_p; ++a) S.ilist[fill[elem[(int64_t)a * n_e + e]]++] = (int32_t)((int64_t)a * n_e + e);
-    }
-    // (i)+(ii) per node: gather (neighbour, code) pairs, sort by neighbour (stable in (e,a,b) order)
-    const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<int32_t> deg(n_n, 0);
-    auto node_pairs = [&](int64_t n, std::vector<std::pair<int32_t, int32_t>>& buf) {
-        buf.clear();
-        for (int32_t t = S.iptr[n]; t < S.iptr[n + 1]; ++t) {
-            const int64_t code = S.ilist[t];
-            const int a = (int)(code / n_e);
-            const int64_t e = code - (int64_t)a * n_e;
-            for (int b = 0; b < n_p; ++b)
-                buf.emplace_back(elem[(int64_t)b * n_e + e], (int32_t)(((int64_t)a * n_p + b) * n_e + e));
-        }
-        std::stable_sort(buf.begin(), buf.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-    };
-    // pass 1: degrees
-    {
-        std::vector<std::thread> th;
-        for (int w = 0; w < nthreads; ++w)
-            th.emplace_back([&, w]() {
-                std::vector<std::pair<int32_t, int32_t>> buf;
-                for (int64_t n = n_n * w / nthreads; n < n_n * (w + 1) / nthreads; ++n) {
-                    node_pairs(n, buf);
-                    int32_t d = 0;
-                    for (size_t i = 0; i < buf.size(); ++i)
-                        if (i == 0 || buf[i].first != buf[i - 1].first) ++d;
-                    deg[n] = d;
-                }
-            });
-        for (auto& t : th) t.join();
-    }
-    S.nptr.assign(n_n + 1, 0);
-    int64_t tot = 0;
-    for (int64_t n = 0; n < n_n; ++n) {
-        if (deg[n] > 0x7fff) return FEP_ERANGE;
-        tot += deg[n];
-        if (tot >= INT32_MAX / 4) return FEP_ERANGE;
-        S.nptr[n + 1] = (int32_t)tot;
-    }
-    const int64_t n_blk = tot;
-    const int64_t n_contrib = (int64_t)n_p * n_p * n_e;
-    S.ncol.resize(n_blk);
-    S.meta.resize(n_blk);
-    S.segptr.assign(n_blk + 1, 0);
-    S.perm.resize(n_contrib);
-    // contributions of node n start at n_p * iptr[n] (each incident (e,a) brings n_p pairs)
-    {
-        std::vector<std::thread> th;
-        for (int w = 0; w < nthreads; ++w)
-            th.emplace_back([&, w]() {
-                std::vector<std::pair<int32_t, int32_t>> buf;
-                for (int64_t n = n_n * w / nthreads; n < n_n * (w + 1) / nthreads; ++n) {
-                    node_pairs(n, buf);
-                    int64_t pos = (int64_t)n_p * S.iptr[n];
-                    int32_t slot = -1;
-                    for (size_t i = 0; i < buf.size(); ++i) {
-                        if (i == 0 || buf[i].first != buf[i - 1].first) {
-                            ++slot;
-                            const int64_t blk = S.nptr[n] + slot;
-                            S.ncol[blk] = buf[i].first;
-                            S.meta[blk] = ((uint32_t)deg[n] << 16) | (buf[i].first == (int32_t)n ? 0x8000u : 0u) | (uint32_t)slot;
-                            S.segptr[blk] = (int32_t)pos;
-                        }
-                        S.perm[pos++] = buf[i].second;
-                    }
-                }
-            });
-        for (auto& t : th) t.join();
-    }
-    S.segptr[n_blk] = (int32_t)n_contrib;
-    return FEP_OK;
-}
+static_assert(fep_host::kSegMax == fep::kSegMax, "tile descriptor layout shared by host and kernels");
 
 template <int NP, int NQ>
 static int launch_geometry(fep_ctx* c) {
@@ -356,7 +272,8 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (fep_set_device(c->device) == FEP_OK) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
-                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tile_fnode0, c->tstart};
+                        c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tdesc, c->tstart,
+                        c->wg_nlist, c->wg_nrng, c->el_nodes, c->slot_counts};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -365,11 +282,33 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     return FEP_OK;
 }
 
+static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int elem_type, int64_t n_e, int64_t n_n,
+                           const int32_t* elements_h, const double* coords_h,
+                           const double* dhatp1_h, const double* dhatp2_h, const double* wf_h);
+
+// Nothing may leave an extern "C" entry point by exception: the host symbolic phase allocates multi-GB std::vectors
+// (std::bad_alloc at BASELINE configs[4] sizes on a small host) -> FEP_ENOMEM instead of std::terminate.
 extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, int64_t n_e, int64_t n_n,
                               const int32_t* elements_h, const double* coords_h,
                               const double* dhatp1_h, const double* dhatp2_h, const double* wf_h) {
     if (!ctx_out) return FEP_EINVAL;
     *ctx_out = nullptr;
+    fep_ctx* c = nullptr;
+    int r;
+    try {
+        r = ctx_create_impl(c, ctx_out, device_id, elem_type, n_e, n_n, elements_h, coords_h, dhatp1_h, dhatp2_h, wf_h);
+    } catch (const std::bad_alloc&) {
+        r = FEP_ENOMEM;
+    } catch (...) {
+        r = FEP_EINVAL;
+    }
+    if (r != FEP_OK) { if (c) fep_ctx_destroy(c); *ctx_out = nullptr; }
+    return r;
+}
+
+static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int elem_type, int64_t n_e, int64_t n_n,
+                           const int32_t* elements_h, const double* coords_h,
+                           const double* dhatp1_h, const double* dhatp2_h, const double* wf_h) {
     int n_p = 0, n_q = 0;
     FEP_TRY(fep_element_shape(elem_type, &n_p, &n_q));
     if (n_e <= 0 || n_n <= 0 || !elements_h || !coords_h || !dhatp1_h || !dhatp2_h || !wf_h) return FEP_EINVAL;
@@ -377,11 +316,12 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     Symbolic S;
     FEP_TRY(build_symbolic(n_p, n_e, n_n, elements_h, S));
     FEP_TRY(fep_set_device(device_id));
-    fep_ctx* c = new (std::nothrow) fep_ctx();
+    c = new (std::nothrow) fep_ctx();
     if (!c) return FEP_ENOMEM;
     c->device = device_id; c->elem_type = elem_type; c->n_p = n_p; c->n_q = n_q;
     c->n_e = n_e; c->n_n = n_n; c->n_int = n_e * n_q; c->n_dof = 2 * n_n;
     c->n_blk = (int64_t)S.ncol.size(); c->nnz = 4 * c->n_blk; c->n_contrib = (int64_t)S.perm.size();
+    for (int64_t n = 0; n < n_n && !c->has_orphans; ++n) c->has_orphans = S.iptr[n + 1] == S.iptr[n];
     // host CSR pattern on DOFs
     c->indptr.resize(c->n_dof + 1);
     c->indices.resize(c->nnz);
@@ -398,7 +338,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     }
     c->indptr[c->n_dof] = (int32_t)c->nnz;
     int r = FEP_OK;
-#define CK(x) if (r == FEP_OK) r = (x)
+#define CK(x) do { if (r == FEP_OK) r = (x); } while (0)
     CK(upload(&c->elem, elements_h, (int64_t)n_p * n_e));
     CK(upload(&c->coords, coords_h, 2 * n_n));
     CK(upload(&c->dh1, dhatp1_h, (int64_t)n_p * n_q));
@@ -411,157 +351,58 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     CK(dmalloc(&c->shear, c->n_int)); CK(dmalloc(&c->bulk, c->n_int)); CK(dmalloc(&c->eta, c->n_int)); CK(dmalloc(&c->c, c->n_int));
     CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
     CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
-    // tiles of whole nodes with at most kBlock node-pair blocks (a node's blocks are consecutive ids): the CSR
-    // values a tile produces are one contiguous range
-    std::vector<int32_t> tstart_all{0};
-    for (int64_t n = 0, cur = 0; n < n_n; ++n) {
-        const int64_t d = S.nptr[n + 1] - S.nptr[n];
-        if (d > kBlock) { r = FEP_ERANGE; break; }
-        if (cur + d > kBlock) { tstart_all.push_back(S.nptr[n]); cur = 0; }
-        cur += d;
-    }
-    tstart_all.push_back((int32_t)c->n_blk);
+    // COO route: tiles of whole nodes with at most kBlock node-pair blocks (csr_reduce_kernel's work units)
+    std::vector<int32_t> tstart_all;
+    CK(fep_host::row_tiles(S, n_n, kBlock, tstart_all));
     {   // P1 runs the node-centric fast path unless FEP_P1_PATH=coo asks for the generic COO route
         const char* pth = std::getenv("FEP_P1_PATH");
         c->p1_node = elem_type == FEP_P1 && !(pth && std::strcmp(pth, "coo") == 0);
     }
     if (c->p1_node) {
-        if (n_e >= (int64_t)1 << 27) r = FEP_ERANGE;
-        std::vector<int32_t> perm2(S.perm.size());
-        for (size_t i = 0; i < S.perm.size(); ++i) {
-            const int64_t code = S.perm[i];
-            const int64_t ab = code / n_e, e = code - ab * n_e;
-            perm2[i] = (int32_t)((e << 4) | ((ab / 3) << 2) | (ab % 3));
+        // gather plan of the node route (host, fep_host.h): tiles, staged element / node lists, codes, descriptors
+        const char* pth = std::getenv("FEP_P1_PATH");
+        auto is = [&](const char* v) { return pth && std::strcmp(pth, v) == 0; };
+        fep_host::P1Options opt;
+        opt.tile = c->tile;
+        opt.allow_lds = !is("node_direct");
+        opt.allow_rng = !is("node_list");
+        opt.allow_pk = !is("node_unpacked");
+        opt.allow_fused = !is("node2k");
+        if (const char* sg = std::getenv("FEP_P1_SEGS")) opt.max_segs = std::max(1, std::min(std::atoi(sg), fep_host::kSegMax));
+        fep_host::P1Plan P;
+        CK(fep_host::build_p1_plan(S, n_e, n_n, elements_h, opt, P));
+        if (r == FEP_OK && std::getenv("FEP_VALIDATE_PLAN")) {
+            const int bad = fep_host::validate_p1_plan(P, S, n_e, n_n, elements_h);
+            if (bad) { std::fprintf(stderr, "[fep] P1 plan fails check %d\n", bad); r = FEP_EINVAL; }
         }
-        CK(upload(&c->perm2, perm2.data(), (int64_t)perm2.size()));
-        CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
-        {   // per-workgroup (`tile` consecutive blocks) sorted unique element lists + local gather codes
-            const int64_t TILE = c->tile;
-            // tiles = runs of WHOLE nodes with at most TILE blocks (a node's blocks are consecutive ids)
-            std::vector<int32_t> tstart{0};
-            for (int64_t n = 0, cur = 0; n < n_n; ++n) {
-                const int64_t d = S.nptr[n + 1] - S.nptr[n];
-                if (d > TILE) { r = FEP_ERANGE; break; }
-                if (cur + d > TILE) { tstart.push_back(S.nptr[n]); cur = 0; }
-                cur += d;
+        if (r == FEP_OK) {
+            c->n_wg_p1 = (int)P.n_wg; c->p1_segs = P.n_segs;
+            c->p1_lds = P.lds; c->lds_L = P.L; c->lds_C = P.C; c->p1_rng = P.rng; c->p1_pk = P.pk;
+            c->p1_fused = P.fused; c->p1_fused_rng = P.fused_rng; c->lds_NL = P.NL;
+            if (const char* fm = std::getenv("FEP_P1_FUSED"))
+                c->fused_mode = std::strcmp(fm, "off") == 0 ? 0 : std::strcmp(fm, "kf") == 0 ? 1 : 2;
+            CK(upload(&c->perm2, P.perm2.data(), (int64_t)P.perm2.size()));
+            CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
+            CK(upload(&c->tdesc, (const int4*)P.tdesc.data(), (int64_t)P.tdesc.size() / 4));
+            if (P.lds) {
+                CK(upload(&c->wg_elist, P.elist_pad.data(), (int64_t)P.elist_pad.size()));
+                CK(upload(&c->perm_l, P.codes_pad.data(), (int64_t)P.codes_pad.size()));
+                if (P.rng) CK(upload(&c->wg_rng, P.rng_tab.data(), (int64_t)P.rng_tab.size()));
+                if (P.pk) CK(upload(&c->pk, (const uint2*)P.pkv.data(), (int64_t)P.pkv.size()));
             }
-            tstart.push_back((int32_t)c->n_blk);
-            const int64_t n_wg = (int64_t)tstart.size() - 1;
-            c->n_wg_p1 = (int)n_wg;
-            std::vector<int32_t> eptr(n_wg + 1, 0);
-            std::vector<std::vector<int32_t>> lists(n_wg);
-            std::vector<uint16_t> perm_l(perm2.size());
-            const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-            std::vector<std::thread> th;
-            for (int w = 0; w < nthreads; ++w)
-                th.emplace_back([&, w]() {
-                    for (int64_t g = n_wg * w / nthreads; g < n_wg * (w + 1) / nthreads; ++g) {
-                        const int64_t b0 = tstart[g], b1 = tstart[g + 1];
-                        const int32_t t0 = S.segptr[b0], t1 = S.segptr[b1];
-                        std::vector<int32_t>& l = lists[g];
-                        l.reserve(t1 - t0);
-                        for (int32_t t = t0; t < t1; ++t) l.push_back(perm2[t] >> 4);
-                        std::sort(l.begin(), l.end());
-                        l.erase(std::unique(l.begin(), l.end()), l.end());
-                        for (int32_t t = t0; t < t1; ++t) {
-                            const int32_t loc = (int32_t)(std::lower_bound(l.begin(), l.end(), perm2[t] >> 4) - l.begin());
-                            perm_l[t] = (uint16_t)((loc << 4) | (perm2[t] & 15));
-                        }
-                    }
-                });
-            for (auto& t : th) t.join();
-            size_t lmax = 0, cmax = 0;
-            for (int64_t g = 0; g < n_wg; ++g) {
-                eptr[g + 1] = eptr[g] + (int32_t)lists[g].size();
-                lmax = std::max(lmax, lists[g].size());
-                const int64_t b0 = tstart[g], b1 = tstart[g + 1];
-                cmax = std::max(cmax, (size_t)(S.segptr[b1] - S.segptr[b0]));
+            if (P.fused) {
+                CK(upload(&c->el_nodes, P.elnodes.data(), (int64_t)P.elnodes.size()));
+                if (P.fused_rng) { CK(upload(&c->wg_nrng, P.nrng_tab.data(), (int64_t)P.nrng_tab.size())); }
+                else { CK(upload(&c->wg_nlist, P.nlist_pad.data(), (int64_t)P.nlist_pad.size())); }
+                CK(dmalloc(&c->slot_counts, 256 * 16));
+                if (r == FEP_OK && hipMemset(c->slot_counts, 0, 256 * 16 * sizeof(unsigned long long)) != hipSuccess) r = FEP_EHIP;
             }
-            c->lds_C = (int)((cmax + 7) & ~(size_t)7);
-            std::vector<int32_t> elist((size_t)eptr[n_wg]);
-            for (int64_t g = 0; g < n_wg; ++g) std::copy(lists[g].begin(), lists[g].end(), elist.begin() + eptr[g]);
-            const char* pth = std::getenv("FEP_P1_PATH");
-            c->lds_L = (int)((lmax + 1) & ~(size_t)1);
-            // 15 doubles per staged element; fall back to the direct-gather kernel when a list would not fit
-            // the staged kernel holds <= 2 elements and <= 4 gather codes per lane in registers
-            c->p1_lds = lmax <= 2 * (size_t)TILE && cmax <= 4 * (size_t)TILE &&
-                        (size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 <= 96 * 1024 &&
-                        !(pth && std::strcmp(pth, "node_direct") == 0);
-            if (c->p1_lds) {
-                // fixed per-tile strides (lds_L list entries, lds_C codes); unused slots repeat a valid entry
-                const int64_t LP = c->lds_L, CP = c->lds_C;
-                std::vector<int32_t> elist_pad((size_t)(n_wg * LP));
-                std::vector<uint16_t> codes_pad((size_t)(n_wg * CP), 0);
-                for (int64_t g = 0; g < n_wg; ++g) {
-                    std::fill(elist_pad.begin() + g * LP, elist_pad.begin() + (g + 1) * LP, lists[g].empty() ? 0 : lists[g][0]);
-                    std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * LP);
-                    const int64_t b0 = tstart[g], b1 = tstart[g + 1];
-                    std::copy(perm_l.begin() + S.segptr[b0], perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * CP);
-                }
-                CK(upload(&c->tstart, tstart.data(), (int64_t)tstart.size()));
-                CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
-                CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
-                // run-length form of the lists: (start, cumulative count) x 8 per tile, if every list fits
-                std::vector<int32_t> rng((size_t)n_wg * 16);
-                bool fits = !(pth && std::strcmp(pth, "node_list") == 0);
-                for (int64_t g = 0; g < n_wg && fits; ++g) {
-                    const std::vector<int32_t>& l = lists[g];
-                    int nr = 0, cum = 0;
-                    int32_t* d = rng.data() + g * 16;
-                    for (size_t i = 0; i < l.size();) {
-                        size_t j = i + 1;
-                        while (j < l.size() && l[j] == l[j - 1] + 1) ++j;
-                        if (nr == 8) { fits = false; break; }
-                        cum += (int)(j - i);
-                        d[2 * nr] = l[i]; d[2 * nr + 1] = cum;
-                        ++nr; i = j;
-                    }
-                    for (; nr < 8; ++nr) { d[2 * nr] = l.empty() ? 0 : l[0]; d[2 * nr + 1] = cum; }
-                }
-                c->p1_rng = fits;
-                if (fits) CK(upload(&c->wg_rng, rng.data(), (int64_t)rng.size()));
-                // packed block descriptors, if every field fits its bit width; lanes sorted by segment length
-                std::vector<uint2> pkv((size_t)c->n_blk);
-                std::vector<int2> fn0((size_t)n_wg, make_int2(0, 0));
-                bool pk_ok = CP <= 2047 && TILE <= 256 && !(pth && std::strcmp(pth, "node_unpacked") == 0);
-                std::vector<int> order(TILE);
-                for (int64_t g = 0; g < n_wg && pk_ok; ++g) {
-                    const int64_t b0 = tstart[g], b1 = tstart[g + 1];
-                    const int32_t t0 = S.segptr[b0];
-                    const int nb = (int)(b1 - b0);
-                    for (int k = 0; k < nb; ++k) order[k] = k;
-                    std::stable_sort(order.begin(), order.begin() + nb, [&](int x, int y) {
-                        return S.segptr[b0 + x + 1] - S.segptr[b0 + x] > S.segptr[b0 + y + 1] - S.segptr[b0 + y];
-                    });
-                    // node index inside the tile of every block (tiles hold whole, consecutive nodes)
-                    int knode = -1;
-                    std::vector<int> node_of(nb);
-                    int32_t first_node = -1;
-                    for (int k = 0; k < nb; ++k) {
-                        if ((S.meta[b0 + k] & 0x7fffu) == 0) ++knode;
-                        node_of[k] = knode;
-                        if ((S.meta[b0 + k] >> 15) & 1u) { if (first_node < 0 || S.ncol[b0 + k] < first_node) first_node = S.ncol[b0 + k]; }
-                    }
-                    fn0[g] = make_int2(first_node < 0 ? 0 : first_node, knode + 1);
-                    if (knode + 1 > 255) { pk_ok = false; break; }
-                    for (int lane = 0; lane < nb; ++lane) {
-                        const int k = order[lane];
-                        const int64_t b = b0 + k;
-                        const uint32_t mt = S.meta[b];
-                        const uint32_t len = (uint32_t)(S.segptr[b + 1] - S.segptr[b]), deg = mt >> 16, slot = mt & 0x7fffu;
-                        const uint32_t diag = (mt >> 15) & 1u;
-                        if (len > 15 || deg > 255 || slot > 255) { pk_ok = false; break; }
-                        if (diag && S.ncol[b] != fn0[g].x + node_of[k]) { pk_ok = false; break; }   // consecutive node ids
-                        pkv[b0 + lane] = make_uint2((uint32_t)(S.segptr[b] - t0) | (len << 11) | (deg << 15) | (slot << 23) | (diag << 31),
-                                                    (uint32_t)k | ((uint32_t)node_of[k] << 8));
-                    }
-                }
-                c->p1_pk = pk_ok;
-                if (pk_ok) {
-                    CK(upload(&c->pk, pkv.data(), (int64_t)pkv.size()));
-                    CK(upload(&c->tile_fnode0, fn0.data(), (int64_t)fn0.size()));
-                }
-            }
+            static const bool verbose = std::getenv("FEP_VERBOSE") != nullptr;
+            if (verbose)
+                std::fprintf(stderr, "[fep] P1 plan: %lld tiles of <= %d blocks in <= %d segment(s), staged elements %lld "
+                             "(%.2f per element, <= %d per tile), staged nodes <= %d, codes <= %d; lds %d rng %d pk %d fused %d/%d\n",
+                             (long long)P.n_wg, P.tile, P.n_segs, (long long)P.staged_total, (double)P.staged_total / (double)n_e,
+                             P.L, P.NL, P.C, (int)P.lds, (int)P.rng, (int)P.pk, (int)P.fused, (int)P.fused_rng);
         }
         CK(dmalloc(&c->geo, 6 * n_e));
         {
@@ -576,59 +417,16 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
         const char* gp = std::getenv("FEP_GEN_PATH");
         const bool want_gn = (elem_type == FEP_P2 || elem_type == FEP_Q1 || elem_type == FEP_Q2) &&
                              gp && std::strcmp(gp, "node") == 0 && r == FEP_OK;
-        for (int TILE : {256, 128}) {
-            if (!want_gn || c->gn) break;
-            // per-tile sorted unique element lists and 16-bit gather codes (local element << 8 | a << 4 | b)
-            const int64_t n_wg = (c->n_blk + TILE - 1) / TILE;
-            std::vector<std::vector<int32_t>> lists(n_wg);
-            std::vector<uint16_t> perm_l(S.perm.size());
-            const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-            std::vector<std::thread> th;
-            std::vector<int> bad(nthreads, 0);
-            for (int w = 0; w < nthreads; ++w)
-                th.emplace_back([&, w]() {
-                    for (int64_t g = n_wg * w / nthreads; g < n_wg * (w + 1) / nthreads; ++g) {
-                        const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
-                        const int32_t t0 = S.segptr[b0], t1 = S.segptr[b1];
-                        std::vector<int32_t>& l = lists[g];
-                        l.reserve(t1 - t0);
-                        for (int32_t t = t0; t < t1; ++t) l.push_back((int32_t)(S.perm[t] % n_e));
-                        std::sort(l.begin(), l.end());
-                        l.erase(std::unique(l.begin(), l.end()), l.end());
-                        if (l.size() > 256) { bad[w] = 1; continue; }
-                        for (int32_t t = t0; t < t1; ++t) {
-                            const int64_t ab = S.perm[t] / n_e, e = S.perm[t] % n_e;
-                            const int32_t loc = (int32_t)(std::lower_bound(l.begin(), l.end(), (int32_t)e) - l.begin());
-                            perm_l[t] = (uint16_t)((loc << 8) | ((int)(ab / n_p) << 4) | (int)(ab % n_p));
-                        }
-                    }
-                });
-            for (auto& t : th) t.join();
-            size_t lmax = 0, cmax = 0;
-            for (int64_t g = 0; g < n_wg; ++g) {
-                lmax = std::max(lmax, lists[g].size());
-                const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
-                cmax = std::max(cmax, (size_t)(S.segptr[b1] - S.segptr[b0]));
+        if (want_gn) {
+            fep_host::GnPlan G;
+            fep_host::build_gn_plan(S, n_p, n_q, n_e, G);
+            if (G.ok) {
+                c->gn = true; c->gn_tile = G.tile; c->lds_L = G.L; c->lds_C = G.C; c->gn_lds = G.lds;
+                CK(upload(&c->wg_elist, G.elist_pad.data(), (int64_t)G.elist_pad.size()));
+                CK(upload(&c->perm_l, G.codes_pad.data(), (int64_t)G.codes_pad.size()));
+                CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
+                c->n_count_blocks = (int)grid_for(c->n_int, kBlock);
             }
-            const int L = (int)lmax, C = (int)((cmax + 7) & ~(size_t)7);
-            const size_t lds = ((size_t)(9 + 2 * n_p) * L * n_q + 2 * (size_t)n_p * n_q + n_q + (n_q & 1)) * sizeof(double) +
-                               (size_t)C * sizeof(uint16_t);
-            bool ok = lmax <= 256 && lds <= 64 * 1024;
-            for (int b : bad) ok = ok && !b;
-            if (!ok) continue;
-            c->gn = true; c->gn_tile = TILE; c->lds_L = L; c->lds_C = C; c->gn_lds = lds;
-            std::vector<int32_t> elist_pad((size_t)(n_wg * L));
-            std::vector<uint16_t> codes_pad((size_t)(n_wg * C), 0);
-            for (int64_t g = 0; g < n_wg; ++g) {
-                std::fill(elist_pad.begin() + g * L, elist_pad.begin() + (g + 1) * L, lists[g].empty() ? 0 : lists[g][0]);
-                std::copy(lists[g].begin(), lists[g].end(), elist_pad.begin() + g * L);
-                const int64_t b0 = g * TILE, b1 = std::min<int64_t>(c->n_blk, b0 + TILE);
-                std::copy(perm_l.begin() + S.segptr[b0], perm_l.begin() + S.segptr[b1], codes_pad.begin() + g * C);
-            }
-            CK(upload(&c->wg_elist, elist_pad.data(), (int64_t)elist_pad.size()));
-            CK(upload(&c->perm_l, codes_pad.data(), (int64_t)codes_pad.size()));
-            CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
-            c->n_count_blocks = (int)grid_for(c->n_int, kBlock);
         }
     }
     {   // interleaved (x, y) per node: the kernels recompute dphi / weight from the coordinates
@@ -685,7 +483,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
 #undef CALL
     }
     if (r == FEP_OK && hipDeviceSynchronize() != hipSuccess) { g_last_hip = (int)hipGetLastError(); r = FEP_EHIP; }
-    if (r != FEP_OK) { fep_ctx_destroy(c); return r; }
+    if (r != FEP_OK) return r;                          // the caller destroys the partial context
     *ctx_out = c;
     return FEP_OK;
 }
@@ -831,13 +629,12 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
 #define NODE_LDS3(TPB, RNG, EPT, PK)                                                                                     \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<false, TPB, RNG, EPT, PK>,                       \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_node_lds_kernel<TPB, RNG, EPT, PK>,                              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((p1_node_lds_kernel<false, TPB, RNG, EPT, PK>), dim3(8 * chunk), dim3(TPB), lds, st,          \
-                           c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,    \
-                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->tstart, c->geo, k_data ? ds : nullptr,      \
-                           f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks, c->blk_counts, counts_d,         \
-                           (long long*)nullptr);                                                                         \
+        hipLaunchKernelGGL((p1_node_lds_kernel<TPB, RNG, EPT, PK>), dim3(8 * chunk), dim3(TPB), lds, st,                 \
+                           c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,              \
+                           (const int4*)c->wg_rng, c->pk, c->tdesc, c->geo, k_data ? ds : nullptr,                       \
+                           f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks, c->blk_counts, counts_d);        \
     } while (0)
 #define NODE_LDS2(TPB, RNG, EPT) do { if (c->p1_pk) NODE_LDS3(TPB, RNG, EPT, true); else NODE_LDS3(TPB, RNG, EPT, false); } while (0)
 #define NODE_LDS(TPB)                                                                                                    \
@@ -907,6 +704,43 @@ static int launch_point(fep_ctx* c, hipStream_t st, const double* u, E0 e0, doub
     return FEP_OK;
 }
 
+// P1, one kernel per step (non-accepting calls with K and/or F wanted): p1_fused_kernel
+static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, const double* ep, double* eout, double* s,
+                           double* ds, uint8_t* indp, double* k_data, double* f_out, unsigned long long* counts_d) {
+    const size_t lds_stage = (((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 + 15) & ~(size_t)15) +
+                             (size_t)c->lds_NL * 2 * sizeof(double2);
+    const size_t lds = std::max(lds_stage, (size_t)c->tile * 3 * sizeof(double2));
+    const int n_wg = c->n_wg_p1;
+    const int chunk = (n_wg + 7) / 8;
+    const bool full = eout || s || ds || indp;
+#define FUSED4(FULL, RNG, EPT, NPT)                                                                                      \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_fused_kernel<FULL, 256, RNG, EPT, NPT>,                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+        hipLaunchKernelGGL((p1_fused_kernel<FULL, 256, RNG, EPT, NPT>), dim3(8 * chunk), dim3(256), lds, st,             \
+                           c->n_e, c->lds_L, c->lds_C, c->lds_NL, c->perm_l, c->wg_elist, (const int4*)c->wg_rng,        \
+                           c->wg_nlist, (const int4*)c->wg_nrng, c->el_nodes, c->pk, c->tdesc, c->xy,                   \
+                           c->p1tab, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu, eout, s, ds, indp, k_data,      \
+                           f_out, n_wg, counts_d ? c->slot_counts : (unsigned long long*)nullptr);                       \
+    } while (0)
+#define FUSED3(FULL, RNG) do {                                                                                           \
+        const bool e1 = c->lds_L <= 256, n1 = c->lds_NL <= 256;                                                          \
+        if (e1 && n1) FUSED4(FULL, RNG, 1, 1); else if (e1) FUSED4(FULL, RNG, 1, 2);                                     \
+        else if (n1) FUSED4(FULL, RNG, 2, 1); else FUSED4(FULL, RNG, 2, 2);                                              \
+    } while (0)
+    if (full) { if (c->p1_fused_rng) FUSED3(true, true); else FUSED3(true, false); }
+    else { if (c->p1_fused_rng) FUSED3(false, true); else FUSED3(false, false); }
+#undef FUSED3
+#undef FUSED4
+    HIP_TRY(hipGetLastError());
+    if (counts_d) {
+        hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(256), 0, st, c->slot_counts, counts_d);
+        HIP_TRY(hipGetLastError());
+    }
+    return FEP_OK;
+}
+
 extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const double* e0_h,
                             double* ep_prev_d, int accept, double* e_out_d, double* s_d, double* ds_d,
                             uint8_t* ind_p_d, double* k_data_d, double* f_out_d, int64_t* counts_d) {
@@ -918,6 +752,17 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
     unsigned long long* cnt = (unsigned long long*)counts_d;
     uint2* blk = cnt ? c->blk_counts : nullptr;
     const E0 e0 = make_e0(e0_h);
+    if ((c->p1_node || c->gn) && c->has_orphans && f_out_d)        // nodes of no element: no block, no lane writes their force
+        HIP_TRY(hipMemsetAsync(f_out_d, 0, (size_t)c->n_dof * sizeof(double), st));
+    const bool point_outputs = e_out_d || s_d || ds_d || ind_p_d;
+    if (c->p1_node && c->p1_fused && !accept && (k_data_d || f_out_d) && c->fused_mode > (point_outputs ? 1 : 0)) {
+        FEP_TRY(prof_mark(c, st));
+        FEP_TRY(prof_mark(c, st));                      // profile slots: [0] = 0, [1] = the fused kernel (+ counter sum), [2] = 0
+        FEP_TRY(launch_p1_fused(c, st, u_d, e0, ep_prev_d, e_out_d, s_d, ds_d, ind_p_d, k_data_d, f_out_d, cnt));
+        FEP_TRY(prof_mark(c, st));
+        FEP_TRY(prof_mark(c, st));
+        return FEP_OK;
+    }
     if (c->p1_node) {
         // the assembly kernel consumes ds / s from HBM: use internal buffers when the caller wants neither
         if (k_data_d && !ds_d) {
@@ -975,6 +820,8 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
     if (!fep_aligned16(f_out_d) || !fep_aligned16(k_data_d)) return FEP_EINVAL;
     FEP_TRY(fep_set_device(c->device));
     hipStream_t st = (hipStream_t)stream;
+    if ((c->p1_node || c->gn) && c->has_orphans && f_out_d)
+        HIP_TRY(hipMemsetAsync(f_out_d, 0, (size_t)c->n_dof * sizeof(double), st));
     if (c->p1_node) {
         FEP_TRY(prof_mark(c, st));
         return launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, nullptr, nullptr);
@@ -1108,32 +955,4 @@ extern "C" int fep_ctx_profile_end(fep_ctx* c, void* stream, double ms_out[3], i
     for (int k = 0; k < 3; ++k) ms_out[k] = n ? acc[k] / n : 0.0;
     if (n_steps) *n_steps = n;
     return FEP_OK;
-}
-
-// Diagnostic (not part of include/fep.h's product surface; used by tools/node_stamps.py): one launch of the
-// stamped build of the P1 assembly kernel; stamps_h receives n_wg x 8 int64 (s_memtime at phase
-// boundaries, blockIdx, staged element count).  Returns the number of workgroups in *n_wg_out.
-extern "C" int fep_debug_p1_node_stamps(fep_ctx* c, const double* ds_d, const double* s_d, double* k_data_d,
-                                        double* f_out_d, long long* stamps_h, int64_t cap, int* n_wg_out) {
-    if (!c || !c->p1_node || !c->p1_lds || !ds_d || !s_d || !k_data_d || !f_out_d || !stamps_h) return FEP_EINVAL;
-    FEP_TRY(fep_set_device(c->device));
-    if (c->tile != 256 || !c->p1_rng || c->lds_L > 256) return FEP_EINVAL;
-    const int n_wg = c->n_wg_p1;
-    if (n_wg_out) *n_wg_out = n_wg;
-    if (cap < (int64_t)n_wg * 8) return FEP_EINVAL;
-    DevBuf st;
-    FEP_TRY(st.alloc((int64_t)n_wg * 8 * sizeof(long long)));
-    const size_t lds = std::max((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t),
-                                (size_t)c->tile * 3 * sizeof(double2));
-    const int chunk = (n_wg + 7) / 8;
-    for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((p1_node_lds_kernel<true, 256, true, 1, false>), dim3(8 * chunk), dim3(kBlock), lds, nullptr,
-                           c->n_blk, c->n_e, c->lds_L, c->lds_C, c->segptr, c->perm_l, c->meta, c->ncol, c->wg_elist,
-                           (const int4*)c->wg_rng, c->pk, c->tile_fnode0, c->tstart, c->geo, ds_d, s_d, k_data_d, f_out_d, n_wg, 0,
-                           (const uint2*)nullptr,
-                           (unsigned long long*)nullptr, st.as<long long>());
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    return st.to(stamps_h, (int64_t)n_wg * 8 * sizeof(long long));
 }

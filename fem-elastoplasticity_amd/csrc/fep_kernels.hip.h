@@ -659,26 +659,75 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 // pk.y: block index in the tile | node index in the tile << 8) instead of segptr x2 + meta + ncol, and the lanes of
 // a tile are SORTED by descending segment length: the diagonal blocks (one contribution per incident element, 6 on
 // a regular mesh, against 2 for an edge block) fill the first wave instead of setting the trip count of all four.
-template <bool DIAG, int TPB, bool RNG, int EPT, bool PK>
+//
+// Tiles (fep_host.h, P1Plan): up to kSegMax segments of consecutive nodes; `tdesc` holds, per tile, 1 + kSegMax int4:
+// (pk_base, n_blocks, n_nodes, n_segments) and per segment (first_block, n_blocks, first_node, n_nodes), read with
+// scalar loads.  The tile's CSR values and forces leave as one contiguous range per segment.  Without PK every tile
+// has exactly one segment (its blocks are first_block + lane).
+constexpr int kSegMax = 4;
+
+struct TileDesc { int4 h, s[kSegMax]; };
+
+__device__ __forceinline__ TileDesc load_tile_desc(const int4* __restrict__ tdesc, int wg) {
+    const int4* d = tdesc + (int64_t)wg * (1 + kSegMax);          // uniform address: scalar loads
+    TileDesc t;
+    t.h = d[0];
+#pragma unroll
+    for (int k = 0; k < kSegMax; ++k) t.s[k] = d[1 + k];
+    return t;
+}
+
+// The tile's LDS output image -> HBM: CSR values (2*nb double2 in tile block order) and forces (nn double2 in tile
+// node order), each segment to its own contiguous range.
+template <int TPB>
+__device__ __forceinline__ void store_tile_outputs(const TileDesc& t, const double2* __restrict__ out2, const double2* __restrict__ fo2,
+                                                   double* __restrict__ data, double* __restrict__ F) {
+    if (data) {
+        const int n2 = 2 * t.h.y;
+        for (int i = threadIdx.x; i < n2; i += TPB) {
+            int j = i, seg = 0;                                   // i < 2 * (sum of the segments' blocks)
+#pragma unroll
+            for (int k = 0; k + 1 < kSegMax; ++k) {
+                const bool adv = seg == k && j >= 2 * t.s[k].y;
+                j = adv ? j - 2 * t.s[k].y : j;
+                seg = adv ? k + 1 : seg;
+            }
+            int64_t fb = t.s[0].x;
+#pragma unroll
+            for (int k = 1; k < kSegMax; ++k) fb = seg == k ? t.s[k].x : fb;
+            reinterpret_cast<double2*>(data + 4 * fb)[j] = out2[i];
+        }
+    }
+    if (F && (int)threadIdx.x < t.h.z) {
+        int j = threadIdx.x, seg = 0;
+#pragma unroll
+        for (int k = 0; k + 1 < kSegMax; ++k) {
+            const bool adv = seg == k && j >= t.s[k].w;
+            j = adv ? j - t.s[k].w : j;
+            seg = adv ? k + 1 : seg;
+        }
+        int64_t fn = t.s[0].z;
+#pragma unroll
+        for (int k = 1; k < kSegMax; ++k) fn = seg == k ? t.s[k].z : fn;
+        reinterpret_cast<double2*>(F + 2 * fn)[j] = fo2[threadIdx.x];
+    }
+}
+
+template <int TPB, bool RNG, int EPT, bool PK>
 __global__ void __launch_bounds__(TPB)
-p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
+p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr,
                    const uint16_t* __restrict__ perm_l, const uint32_t* __restrict__ meta,
                    const int32_t* __restrict__ ncol,
                    const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
-                   const uint2* __restrict__ pk, const int2* __restrict__ tile_fnode0,
-                   const int32_t* __restrict__ tstart,
+                   const uint2* __restrict__ pk, const int4* __restrict__ tdesc,
                    const double* __restrict__ geo,
                    const double* __restrict__ DS, const double* __restrict__ S,
                    double* __restrict__ data, double* __restrict__ F,
                    int n_wg, int n_count_blocks, const uint2* __restrict__ blk_counts,
-                   unsigned long long* __restrict__ counts_out, long long* __restrict__ stamps) {
-    // DIAG build only (never timed, never shipped in a step): lane 0 stamps the phase boundaries with
-    // s_memtime into stamps[wg*8 + k]; the values leave the kernel through that buffer alone.
-    long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
-    if (DIAG) st0 = (long long)__builtin_amdgcn_s_memtime();
+                   unsigned long long* __restrict__ counts_out) {
     extern __shared__ __attribute__((aligned(16))) double rec[];      // [15][L]
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with a
-    // private L2.  Give every XCD one contiguous eighth of the node blocks, so that the element rows
+    // private L2.  Give every XCD one contiguous eighth of the tiles, so that the element rows
     // re-staged by the workgroups of the next node row hit in the SAME L2 instead of the fabric.
     const int chunk = (n_wg + 7) >> 3;
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
@@ -688,11 +737,9 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     // L entries, gather codes: C entries, unused slots repeat a valid entry), so all first-level
     // addresses are functions of (tile, lane) and go out together at kernel entry; the operand loads
     // follow as soon as the list entries land.
-    // tiles hold whole nodes: blocks [tstart[wg], tstart[wg+1]), at most TPB of them, so the CSR values and the
-    // force entries a tile produces form ONE contiguous range each
-    const int64_t sb0 = tstart[wg];
-    const int nb = tstart[wg + 1] - (int)sb0;
-    const int64_t sb = sb0 + threadIdx.x;
+    const TileDesc td = load_tile_desc(tdesc, wg);
+    const int nb = td.h.y;
+    const int64_t sb = PK ? (int64_t)td.h.x + threadIdx.x : (int64_t)td.s[0].x + threadIdx.x;
     const bool live = (int)threadIdx.x < nb;
     constexpr int CWPT = 2;                             // 32-bit words of gather codes per lane (2 codes each;
                                                         // host guarantees C <= 2*CWPT*TPB and C even)
@@ -718,7 +765,6 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
             el[r] = wg_elist[(int64_t)wg * L + (i < L ? i : 0)];
         }
     }
-    if (DIAG) { st1 = (long long)__builtin_amdgcn_s_memtime(); }
     // (2) operand loads.  Wave-uniform guard: a wave whose 64 slots all lie past the list issues nothing
     // (with L = 150 of 256 slots that is one wave in four: the kernel's time follows its vector-memory
     // instruction count); inside a wave every lane loads (slots past the list repeat a valid element).
@@ -736,7 +782,6 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
         }
         if (S) { sv[r][0] = S[e]; sv[r][1] = S[n_e + e]; sv[r][2] = S[2 * n_e + e]; }
     }
-    if (DIAG) { st2 = (long long)__builtin_amdgcn_s_memtime(); }
     // (3) the lane's block descriptors and the tile's gather codes: independent of (1)-(2), consumed last
     int32_t beg, end, ncol_sb = -1;
     uint32_t m;
@@ -791,9 +836,7 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     __shared__ int32_t t0_sh;
     const bool is_diag = (m >> 15) & 1u;
     if (!PK && threadIdx.x == 0) t0_sh = beg;
-    if (DIAG) { __builtin_amdgcn_s_waitcnt(0); st3 = (long long)__builtin_amdgcn_s_memtime(); }   // this wave's staging done
     __syncthreads();
-    if (DIAG) st4 = (long long)__builtin_amdgcn_s_memtime();                                       // barrier released
     int32_t t0, fnode_k = -1;
     if (PK) {
         t0 = 0;                                        // pk holds tile-local code offsets
@@ -833,31 +876,257 @@ p1_node_lds_kernel(int64_t n_blk, int64_t n_e, int L, int C, const int32_t* __re
     if (live && data) {
         const int64_t sl = m & 0x7fffu, deg = m >> 16;
         const int blk = PK ? (int)(pk_y & 255u) : (int)threadIdx.x;   // block index inside the tile
-        const int rel = 4 * blk - 2 * (int)sl;                   // = CSR position - 4*sb0, always even
+        const int rel = 4 * blk - 2 * (int)sl;                   // = CSR position - 4*(first block), always even
         out2[rel >> 1] = make_double2(k00, k01);
         out2[(rel >> 1) + (int)deg] = make_double2(k10, k11);
     }
     double2* fo2 = out2 + 2 * TPB;
     if (PK) { if (want_f) fo2[fnode_k] = make_double2(f0, f1); }
     __syncthreads();
-    if (data) {
-        double2* dst = reinterpret_cast<double2*>(data + 4 * sb0);
-        for (int i = threadIdx.x; i < 2 * nb; i += TPB) dst[i] = out2[i];
-    }
-    if (F != nullptr && S != nullptr) {
-        if (PK) {
-            const int2 tf = tile_fnode0[wg];           // (first node of the tile, number of nodes)
-            double2* dstf = reinterpret_cast<double2*>(F + 2 * (int64_t)tf.x);
-            if ((int)threadIdx.x < tf.y) dstf[threadIdx.x] = fo2[threadIdx.x];
-        } else if (want_f) {
-            *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol_sb) = make_double2(f0, f1);
+    store_tile_outputs<TPB>(td, out2, fo2, data, (PK && S != nullptr) ? F : nullptr);
+    if (!PK && want_f) *reinterpret_cast<double2*>(F + 2 * (int64_t)ncol_sb) = make_double2(f0, f1);
+}
+
+// ---------------------------------------------------------------------------------------
+// P1, ONE kernel per step (non-accepting calls): the assembly kernel above with the return map moved into its
+// staging phase, so that s / ds never make the round trip through HBM (and are not written at all when the caller
+// does not ask for them: a Newton iterate reads K and F only, DP:1043-1066).
+//
+// A tile = 256 node-pair blocks of ~36 consecutive nodes, as in p1_node_lds_kernel.  What is new:
+//   * the NODES its ~150 staged elements touch (~110) are staged once per tile: coordinates and displacements go to
+//     LDS with one 16-byte load each per node (`nrng`: <= 8 runs of consecutive node ids, scalar loads; or the
+//     list `wg_nlist`), instead of 6 dependent 16-byte gathers per staged element;
+//   * per staged element one 4-byte word `el_nodes` = its three tile-local node indices (10 bits each) and the
+//     OWNER bit: every element is staged by ~2 tiles, exactly one of them (the first in tile order) writes the
+//     element's s / ds / ind_p / strain and counts its branch;
+//   * the lane of a staged element reads its nodes from LDS, forms the P1 geometry (p1_geometry: bit-identical to
+//     geometry_kernel), the strain and the return map (the arithmetic of p1_point_kernel, statement by statement),
+//     and leaves w*DS (6), w*s (3), dphi (6) in LDS for the gather phase, which is p1_node_lds_kernel's.
+// K and F are bit-identical to the two-kernel route (same operands, same summation order).
+// Branch counters: wave ballot -> LDS -> one atomic pair per tile into 256 slots on lines of their own
+// (`slot_counts`, summed and re-zeroed by counts_finalize_kernel): integer sums, deterministic.
+// Accepting calls (plastic strain updated in place) keep the two-kernel route: a neighbour tile could otherwise
+// read an element's updated plastic strain.
+// ---------------------------------------------------------------------------------------
+template <bool FULL, int TPB, bool RNG, int EPT, int NPT>
+__global__ void __launch_bounds__(TPB)
+p1_fused_kernel(int64_t n_e, int L, int C, int NL,
+                const uint16_t* __restrict__ perm_l, const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
+                const int32_t* __restrict__ wg_nlist, const int4* __restrict__ nrng,
+                const uint32_t* __restrict__ el_nodes, const uint2* __restrict__ pk, const int4* __restrict__ tdesc,
+                const double* __restrict__ xy, P1Tab tab, const double* __restrict__ U, E0 e0,
+                const double* __restrict__ ep,
+                const double* __restrict__ shear, const double* __restrict__ bulk,
+                const double* __restrict__ eta, const double* __restrict__ cc, MatU mu,
+                double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
+                double* __restrict__ data, double* __restrict__ F, int n_wg, unsigned long long* __restrict__ slot_counts) {
+    extern __shared__ __attribute__((aligned(16))) double rec[];      // [15][L] | codes | node coordinates | node displacements
+    __shared__ unsigned int sc[2];
+    const int chunk = (n_wg + 7) >> 3;                                // XCD-aware tile order (see p1_node_lds_kernel)
+    const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (wg >= n_wg) return;
+    const TileDesc td = load_tile_desc(tdesc, wg);
+    const int nb = td.h.y;
+    const int64_t sb = (int64_t)td.h.x + threadIdx.x;                  // lane of the tile -> its packed descriptor
+    const bool live = (int)threadIdx.x < nb;
+    constexpr int CWPT = 2;
+    if (threadIdx.x == 0) { sc[0] = 0u; sc[1] = 0u; }
+    // (1) ids of the lane's element slots and node slots: functions of (tile, lane) through scalar loads
+    int64_t el[EPT];
+    int64_t nd[NPT];
+    if (RNG) {
+        const int4* d = rng + (int64_t)wg * 4;
+        const int4 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+        const int st[8] = {d0.x, d0.z, d1.x, d1.z, d2.x, d2.z, d3.x, d3.z};
+        const int cu[8] = {d0.y, d0.w, d1.y, d1.w, d2.y, d2.w, d3.y, d3.w};
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            int e = st[0] + i;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) e = i >= cu[k - 1] ? st[k] + (i - cu[k - 1]) : e;
+            el[r] = i < cu[7] ? e : st[0];
+        }
+        const int4* dn = nrng + (int64_t)wg * 4;
+        const int4 n0 = dn[0], n1 = dn[1], n2 = dn[2], n3 = dn[3];
+        const int sn[8] = {n0.x, n0.z, n1.x, n1.z, n2.x, n2.z, n3.x, n3.z};
+        const int cn[8] = {n0.y, n0.w, n1.y, n1.w, n2.y, n2.w, n3.y, n3.w};
+#pragma unroll
+        for (int r = 0; r < NPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            int n = sn[0] + i;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) n = i >= cn[k - 1] ? sn[k] + (i - cn[k - 1]) : n;
+            nd[r] = i < cn[7] ? n : sn[0];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            el[r] = wg_elist[(int64_t)wg * L + (i < L ? i : 0)];
+        }
+#pragma unroll
+        for (int r = 0; r < NPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            nd[r] = wg_nlist[(int64_t)wg * NL + (i < NL ? i : 0)];
         }
     }
-    if (DIAG && threadIdx.x == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        long long* o = stamps + (int64_t)wg * 8;
-        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = (long long)__builtin_amdgcn_s_memtime();
-        o[6] = blockIdx.x; o[7] = L;
+    // (2) loads, all issued before the first use: node data, the slots' node words / plastic strain / materials
+    double2 nxy[NPT], nu[NPT];
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+        if (r * TPB + (int)(threadIdx.x & ~63u) >= NL) continue;     // wave-uniform: idle waves issue nothing
+        nxy[r] = *reinterpret_cast<const double2*>(xy + 2 * nd[r]);
+        nu[r] = *reinterpret_cast<const double2*>(U + 2 * nd[r]);
+    }
+    uint32_t enw[EPT];
+    double pv[EPT][4], mv[EPT][4];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        if (r * TPB + (int)(threadIdx.x & ~63u) >= L) continue;
+        const int i = r * TPB + (int)threadIdx.x;
+        const int64_t e = el[r];
+        enw[r] = el_nodes[(int64_t)wg * L + (i < L ? i : 0)];
+        if (ep) { pv[r][0] = ep[e]; pv[r][1] = ep[n_e + e]; pv[r][2] = ep[2 * n_e + e]; pv[r][3] = ep[3 * n_e + e]; }
+        else { pv[r][0] = 0.0; pv[r][1] = 0.0; pv[r][2] = 0.0; pv[r][3] = 0.0; }
+        if (!mu.on) { mv[r][0] = shear[e]; mv[r][1] = bulk[e]; mv[r][2] = eta[e]; mv[r][3] = cc[e]; }
+    }
+    // (3) the lane's block descriptor and the tile's gather codes (consumed last)
+    const uint2 w2 = live ? pk[sb] : make_uint2(0u, 0u);
+    const int CW = C >> 1;
+    const uint32_t* codes_w = reinterpret_cast<const uint32_t*>(perm_l) + (int64_t)wg * CW;
+    uint32_t cd[CWPT];
+#pragma unroll
+    for (int r = 0; r < CWPT; ++r) {
+        const int i = r * TPB + (int)threadIdx.x;
+        cd[r] = 0u;
+        if (r * TPB + (int)(threadIdx.x & ~63u) < CW) cd[r] = codes_w[i < CW ? i : 0];
+    }
+    // (4) node data and codes -> LDS
+    uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
+    uint32_t* codes32 = reinterpret_cast<uint32_t*>(rec + 15 * L);
+    double2* lxy = reinterpret_cast<double2*>(reinterpret_cast<char*>(rec) + (((size_t)15 * L * 8 + (size_t)C * 2 + 15) & ~(size_t)15));
+    double2* lu = lxy + NL;
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+        const int i = r * TPB + (int)threadIdx.x;
+        if (i < NL) { lxy[i] = nxy[r]; lu[i] = nu[r]; }
+    }
+#pragma unroll
+    for (int q = 0; q < CWPT; ++q) {
+        const int ci = q * TPB + (int)threadIdx.x;
+        if (ci < CW) codes32[ci] = cd[q];
+    }
+    __syncthreads();
+    // (5) per staged element: geometry, strain, return map (p1_point_kernel's statements), operands -> LDS
+    unsigned int n_sm = 0u, n_ap = 0u;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int i = r * TPB + (int)threadIdx.x;
+        int branch = 0;
+        bool own = false;
+        if (i < L) {
+            const uint32_t wv = enw[r];
+            const int64_t e = el[r];
+            own = (wv >> 30) & 1u;
+            const int i0 = (int)(wv & 1023u), i1 = (int)((wv >> 10) & 1023u), i2 = (int)((wv >> 20) & 1023u);
+            const double2 c0 = lxy[i0], c1 = lxy[i1], c2 = lxy[i2];
+            const double2 u0 = lu[i0], u1 = lu[i1], u2 = lu[i2];
+            double d1[3], d2[3], w;
+            p1_geometry(tab, c0, c1, c2, d1, d2, w);
+            double ev[3];                                            // DP:1043, local node order
+            ev[0] = d1[0] * u0.x + d1[1] * u1.x + d1[2] * u2.x;
+            ev[1] = d2[0] * u0.y + d2[1] * u1.y + d2[2] * u2.y;
+            ev[2] = (d2[0] * u0.x + d1[0] * u0.y) + (d2[1] * u1.x + d1[1] * u1.y) + (d2[2] * u2.x + d1[2] * u2.y);
+            double p[4] = {pv[r][0], pv[r][1], pv[r][2], pv[r][3]};
+            double s[4], d[6];
+            const double m_sh = mu.on ? mu.shear : mv[r][0], m_bu = mu.on ? mu.bulk : mv[r][1];
+            const double m_eta = mu.on ? mu.eta : mv[r][2], m_c = mu.on ? mu.c : mv[r][3];
+            branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, false, s, d);
+            if (FULL && own) {
+                store_point(e, n_e, s, d, branch, S, DS, indp);
+                if (Eout) { Eout[e] = ev[0]; Eout[n_e + e] = ev[1]; Eout[2 * n_e + e] = ev[2]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rec[k * L + i] = w * d[k];
+            rec[6 * L + i] = w * s[0]; rec[7 * L + i] = w * s[1]; rec[8 * L + i] = w * s[2];
+            rec[9 * L + i] = d1[0];  rec[10 * L + i] = d1[1]; rec[11 * L + i] = -(d1[0] + d1[1]);   // as the 48-byte record
+            rec[12 * L + i] = d2[0]; rec[13 * L + i] = d2[1]; rec[14 * L + i] = -(d2[0] + d2[1]);
+        }
+        if (slot_counts) {                                           // uniform
+            n_sm += (unsigned int)__popcll(__ballot(own && branch == 1));
+            n_ap += (unsigned int)__popcll(__ballot(own && branch == 2));
+        }
+    }
+    if (slot_counts && (threadIdx.x & 63) == 0) {
+        if (n_sm) atomicAdd(&sc[0], n_sm);
+        if (n_ap) atomicAdd(&sc[1], n_ap);
+    }
+    __syncthreads();
+    if (slot_counts && threadIdx.x == 0) {
+        unsigned long long* slot = slot_counts + (size_t)(wg & 255) * 16;
+        if (sc[0]) atomicAdd(&slot[0], (unsigned long long)sc[0]);
+        if (sc[1]) atomicAdd(&slot[1], (unsigned long long)sc[1]);
+    }
+    // (6) gather: p1_node_lds_kernel's, packed descriptors
+    const uint32_t wd = w2.x;
+    const uint32_t pk_y = w2.y;
+    const int32_t beg = (int32_t)(wd & 2047u);
+    const int32_t end = beg + (int32_t)((wd >> 11) & 15u);
+    const uint32_t deg = (wd >> 15) & 255u, slot_s = (wd >> 23) & 255u;
+    const bool is_diag = (wd >> 31) != 0u;
+    const int fnode_k = is_diag ? (int)((pk_y >> 8) & 255u) : -1;
+    const bool want_f = live && is_diag && F != nullptr;
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0, f0 = 0.0, f1 = 0.0;
+    if (live) {
+        for (int32_t t = beg; t < end; ++t) {
+            const unsigned code = codes[t];
+            const int i = code >> 4, a = (code >> 2) & 3, b = code & 3;
+            const double a1 = rec[(9 + a) * L + i], a2 = rec[(12 + a) * L + i];
+            const double b1 = rec[(9 + b) * L + i], b2 = rec[(12 + b) * L + i];
+            if (data) {
+                const double D00 = rec[i], D01 = rec[L + i], D02 = rec[2 * L + i];
+                const double D11 = rec[3 * L + i], D12 = rec[4 * L + i], D22 = rec[5 * L + i];
+                const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
+                const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+                k00 += r00 * b1 + r02 * b2;
+                k01 += r01 * b2 + r02 * b1;
+                k10 += r10 * b1 + r12 * b2;
+                k11 += r11 * b2 + r12 * b1;
+            }
+            if (want_f) {
+                f0 += a1 * rec[6 * L + i] + a2 * rec[8 * L + i];
+                f1 += a2 * rec[7 * L + i] + a1 * rec[8 * L + i];
+            }
+        }
+    }
+    __syncthreads();                                   // every lane is done reading the staged operands
+    double2* out2 = reinterpret_cast<double2*>(rec);
+    if (live && data) {
+        const int blk = (int)(pk_y & 255u);
+        const int rel = 4 * blk - 2 * (int)slot_s;
+        out2[rel >> 1] = make_double2(k00, k01);
+        out2[(rel >> 1) + (int)deg] = make_double2(k10, k11);
+    }
+    double2* fo2 = out2 + 2 * TPB;
+    if (want_f) fo2[fnode_k] = make_double2(f0, f1);
+    __syncthreads();
+    store_tile_outputs<TPB>(td, out2, fo2, data, F);
+}
+
+// counts_out[0..1] = sum of the 256 slots (stride 16 words) of p1_fused_kernel; the slots are zeroed for the next step.
+__global__ void __launch_bounds__(256)
+counts_finalize_kernel(unsigned long long* __restrict__ slot_counts, unsigned long long* __restrict__ counts_out) {
+    __shared__ unsigned long long part[2][4];
+    unsigned long long* slot = slot_counts + (size_t)threadIdx.x * 16;
+    unsigned long long a = slot[0], b = slot[1];
+    slot[0] = 0ull; slot[1] = 0ull;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts_out[0] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        counts_out[1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
     }
 }
 

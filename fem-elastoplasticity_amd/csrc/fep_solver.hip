@@ -10,6 +10,7 @@
 // node n hold, back to back, deg(n) pairs (k_r0, k_r1) for the sorted neighbour nodes.  Constrained DOFs are
 // masked out (rows and columns), the solution is 0 there.  M = the 2x2 node blocks of K[Q][:,Q].
 #include "fep_common.h"
+#include "fep_host.h"
 
 #include <algorithm>
 #include <cmath>
@@ -445,8 +446,22 @@ extern "C" int fep_solver_destroy(fep_solver* s) {
     return FEP_OK;
 }
 
+static int solver_create_impl(fep_solver** out, int device_id, int64_t n_n, const int32_t* indptr_h,
+                              const int32_t* indices_h, const uint8_t* free_dof_h);
+
 extern "C" int fep_solver_create(fep_solver** out, int device_id, int64_t n_n, const int32_t* indptr_h,
                                  const int32_t* indices_h, const uint8_t* free_dof_h) {
+    try {                                               // host vectors of the pattern check: no exception leaves the C ABI
+        return solver_create_impl(out, device_id, n_n, indptr_h, indices_h, free_dof_h);
+    } catch (const std::bad_alloc&) {
+        return FEP_ENOMEM;
+    } catch (...) {
+        return FEP_EINVAL;
+    }
+}
+
+static int solver_create_impl(fep_solver** out, int device_id, int64_t n_n, const int32_t* indptr_h,
+                              const int32_t* indices_h, const uint8_t* free_dof_h) {
     if (!out) return FEP_EINVAL;
     *out = nullptr;
     if (n_n <= 0 || !indptr_h || !indices_h || !free_dof_h) return FEP_EINVAL;
@@ -743,28 +758,11 @@ extern "C" int fep_solver_amg_pcg_dev(fep_solver* s, void* stream, const double*
 // neighbours are all free, pass 2 attaches the rest to a neighbouring aggregate (or makes singletons).
 extern "C" int fep_aggregate_host(int64_t n, const int32_t* indptr, const int32_t* indices, int32_t* agg_out,
                                   int64_t* n_agg_out) {
-    if (n <= 0 || !indptr || !indices || !agg_out || !n_agg_out) return FEP_EINVAL;
-    std::vector<int32_t> agg((size_t)n, -1);
-    int32_t na = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        if (agg[i] >= 0) continue;
-        bool free_nb = true;
-        for (int32_t t = indptr[i]; t < indptr[i + 1] && free_nb; ++t) {
-            if (indices[t] < 0 || indices[t] >= n) return FEP_ERANGE;
-            free_nb = agg[indices[t]] < 0;
-        }
-        if (!free_nb) continue;
-        for (int32_t t = indptr[i]; t < indptr[i + 1]; ++t) agg[indices[t]] = na;
-        agg[i] = na++;
+    try {
+        return fep_host::aggregate(n, indptr, indices, agg_out, n_agg_out);
+    } catch (const std::bad_alloc&) {
+        return FEP_ENOMEM;
+    } catch (...) {
+        return FEP_EINVAL;
     }
-    std::vector<int32_t> fin(agg);
-    for (int64_t i = 0; i < n; ++i) {
-        if (agg[i] >= 0) continue;
-        int32_t a = -1;
-        for (int32_t t = indptr[i]; t < indptr[i + 1] && a < 0; ++t) a = agg[indices[t]];
-        fin[i] = a >= 0 ? a : na++;
-    }
-    std::memcpy(agg_out, fin.data(), (size_t)n * sizeof(int32_t));
-    *n_agg_out = na;
-    return FEP_OK;
 }

@@ -63,9 +63,11 @@ class Partition:
         return F_local
 
     # ---- device-resident exchange (torch tensors on the rank's GPU; RCCL) --------------------------
-    def exchange_force_(self, F_local_t, group=None, stream=None):
+    def exchange_force_(self, F_local_t, group=None):
         """In-place: interface DOFs of the local force tensor become the sum over all ranks.
-        pack kernel (other ranks' slots written as zero) -> all-reduce -> unpack kernel."""
+        pack kernel (other ranks' slots written as zero) -> all-reduce -> unpack kernel, all three on torch's
+        CURRENT stream of the tensor's device (`with torch.cuda.stream(s):` selects another one; the collective
+        follows torch's current stream, so the kernels must too)."""
         import torch
         import torch.distributed as dist
         from . import _lib
@@ -77,7 +79,7 @@ class Partition:
                        torch.from_numpy(self.iface_local_dofs.astype(np.int32)).to(dev),
                        torch.empty(2 * self.n_iface, dtype=torch.float64, device=dev))
         pack, slot, loc, buf = self._t
-        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        st = torch.cuda.current_stream(dev).cuda_stream
         l = _lib.lib()
         _lib.check(l.fep_gather_f64(dev.index, st, buf.numel(), F_local_t.data_ptr(), pack.data_ptr(), buf.data_ptr()),
                    'fep_gather_f64')

@@ -41,3 +41,30 @@ def relerr(a, b):
     d = np.abs(a - b).max() if a.size else 0.0
     s = max(np.abs(b).max() if b.size else 0.0, 1e-300)
     return d / s
+
+
+def relerr_points(a, b):
+    """Worst integration point: max over points k of  max_i |a[i,k] - b[i,k]| / max_i |b[i,k]|  for (rows, n_int)
+    arrays (a point whose reference column is all zero - the apex tangent - must be reproduced exactly: its error
+    counts as absolute).  `relerr` scales with the array's global maximum and hides errors in small points."""
+    a = np.asarray(a, dtype=float).reshape(-1, np.shape(a)[-1])
+    b = np.asarray(b, dtype=float).reshape(-1, np.shape(b)[-1])
+    if a.size == 0:
+        return 0.0
+    d = np.abs(a - b).max(axis=0)
+    s = np.abs(b).max(axis=0)
+    return float(np.where(s > 0, d / np.where(s > 0, s, 1.0), d).max())
+
+
+def relerr_rows(A, B):
+    """Worst matrix row: max over rows i of  max_j |A_ij - B_ij| / max_j |B_ij|  (dense or SciPy sparse, same shape)."""
+    import scipy.sparse as ssp
+    if ssp.issparse(A) or ssp.issparse(B):
+        A, B = ssp.csr_matrix(A), ssp.csr_matrix(B)
+        D = abs(A - B).tocsr()
+        d = np.asarray(D.max(axis=1).todense()).ravel()
+        s = np.asarray(abs(B).max(axis=1).todense()).ravel()
+    else:
+        d = np.abs(np.asarray(A) - np.asarray(B)).max(axis=1)
+        s = np.abs(np.asarray(B)).max(axis=1)
+    return float(np.where(s > 0, d / np.where(s > 0, s, 1.0), d).max()) if d.size else 0.0

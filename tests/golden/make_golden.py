@@ -245,11 +245,13 @@ def gen_hotpath(R):
     save('hotpath_dp', **arrs)
 
 
-def gen_dp_trace(R):
-    """The reference's own demo (Plasticity2D_DP/sandbox.py: P1 level 1), run
-    unmodified with recording hooks on module attributes."""
+def _dp_trace(R, t):
+    """The reference's own demo driver `elasticity_fem(element_type, level=1)` (DP:901-1131), run unmodified
+    with recording hooks on module attributes (Plasticity2D_DP/sandbox.py runs it for P1)."""
     m = R['dp']
-    rec = {'U': [], 'counts': [], 'calls': 0, 'accept_E': []}
+    et = m.LagrangeElementType[t]
+    n_n = m.assemble_mesh(1, et, 10)['coordinates'].shape[1]
+    rec = {'U': [], 'counts': [], 'calls': 0, 'accept_s': []}
     orig_ccp = m.construct_constitutive_problem
     orig_fc = m.flatten_col
 
@@ -257,7 +259,7 @@ def gen_dp_trace(R):
         rec['calls'] += 1
         r = orig_ccp(e, ep_prev, shear, bulk, eta, c, apply_plastic_strain=apply_plastic_strain)
         if apply_plastic_strain:
-            rec['accept_s'] = rec.get('accept_s', []) + [r['s'].copy()]
+            rec['accept_s'].append(r['s'].copy())
             rec['U'].append(rec['last_fc'])      # flatten_col(U) at DP:1095 precedes the accepting call
             rec['accept_ep'] = r['ep'].copy()
         return r
@@ -275,7 +277,7 @@ def gen_dp_trace(R):
                 rec['counts'].append((int(g.group(1)), int(g.group(2))))
 
     def fc(v):
-        if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[0] == 2 and v.shape[1] == 441:
+        if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[0] == 2 and v.shape[1] == n_n:
             rec['last_fc'] = np.array(v, copy=True)
         return orig_fc(v)
 
@@ -291,18 +293,146 @@ def gen_dp_trace(R):
     t0 = time.time()
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
-        m.elasticity_fem(m.LagrangeElementType.P1, 1, draw=False)
+        m.elasticity_fem(et, 1, draw=False)
     m.construct_constitutive_problem = orig_ccp
     m.flatten_col = orig_fc
     logging.getLogger().removeHandler(h)
     logging.disable(logging.CRITICAL)
-    # flatten_col(dU) etc. are also (2,441); accepted U are the ones seen right before an accepting call.
-    print(f'  dp trace: {time.time() - t0:.1f}s, calls={rec["calls"]}, zeta steps={len(rec["zeta"])}')
+    # flatten_col(dU) etc. are also (2,n_n); accepted U are the ones seen right before an accepting call.
+    print(f'  dp trace {t}: {time.time() - t0:.1f}s, calls={rec["calls"]}, zeta steps={len(rec["zeta"])}, '
+          f'accepted={len(rec["U"])}, last counts={rec["counts"][-1]}')
+    return rec
+
+
+def gen_dp_trace(R):
+    rec = _dp_trace(R, 'P1')
     save('dp_p1_level1_trace',
          zeta=np.array(rec['zeta']), pressure=np.array(rec['pressure']),
          counts=np.array(rec['counts']), n_calls=np.array(rec['calls']),
          accept_s=np.array(rec['accept_s'])[[0, 7, 15]], accept_steps=np.array([0, 7, 15]),
          U_accepted=np.array(rec['U']), Ep_final=rec['accept_ep'])
+
+
+def gen_dp_trace_types(R, types=('Q1', 'Q2', 'P2')):
+    """The same driver for the other element types `elasticity_fem` accepts (DP:901-903, 945), level 1
+    (Q1 6 s, Q2 83 s, P2 138 s in this container).  Per type: the load history, the counters the
+    reference logs, every accepted displacement, the stress of the first and the last accepted step and the
+    final plastic strain."""
+    for t in types:
+        rec = _dp_trace(R, t)
+        last = len(rec['accept_s']) - 1
+        save(f'dp_{t.lower()}_level1_trace',
+             zeta=np.array(rec['zeta']), pressure=np.array(rec['pressure']),
+             counts=np.array(rec['counts']), n_calls=np.array(rec['calls']),
+             accept_s=np.array(rec['accept_s'])[[0, last]], accept_steps=np.array([0, last]),
+             U_accepted=np.array(rec['U']), Ep_final=rec['accept_ep'])
+
+
+def gen_transform(R):
+    """`transform` (DP:760-816): integration-point field -> nodal field, on small jiggled meshes."""
+    m = R['dp']
+    rng = np.random.default_rng(31)
+    arrs = {}
+    for t, N in (('P1', 7), ('P2', 5), ('Q1', 6), ('Q2', 4)):
+        et, elem, coord = _jiggled_mesh(m, t, N, rng)
+        xi, wf = m.get_quadrature_volume(et)
+        _, d1, d2 = m.get_local_basis_volume(et, xi)
+        n_int = elem.shape[1] * wf.size
+        shear, bulk, _, _ = dp_materials(n_int)
+        _, _, w, *_ = m.get_elastic_stiffness_matrix(elem.copy(), coord, shear, bulk, d1, d2, wf)
+        q = rng.normal(0, 1, size=n_int) * 1e3 + 250.0
+        qn = np.asarray(m.transform(q, elem, w)).ravel()
+        arrs.update({f'{t}_elements': elem, f'{t}_coordinates': coord, f'{t}_weight': np.asarray(w),
+                     f'{t}_q_int': q, f'{t}_q_node': qn})
+    save('transform', **arrs)
+
+
+def _tsx_consts():
+    young, nu = 60000, 0.2                                                       # TSX:1663-1672
+    G = young / (2 * (1 + nu)); Kb = young / (3 * (1 - 2 * nu))
+    fr = 49 * np.pi / 180
+    eta0 = 3 * np.tan(fr) / np.sqrt(9 + 12 * np.tan(fr) ** 2)
+    c0 = 3 * 18.7 / np.sqrt(9 + 12 * np.tan(fr) ** 2)
+    s0 = np.array([-45.0, -11.0, 0.0, -60.0]).reshape((-1, 1))                   # TSX:1675
+    tr0 = s0[0] + s0[1] + s0[3]
+    e_init = np.array([-nu * tr0 + (1 + nu) * s0[0], -nu * tr0 + (1 + nu) * s0[1], [0.0],
+                       -nu * tr0 + (1 + nu) * s0[3]], dtype=float).reshape((-1, 1)) / young   # TSX:1677-1681
+    return G, Kb, eta0, c0, s0, e_init
+
+
+def _tsx_setup(m, et_name, co, el):
+    G, Kb, *_ = _tsx_consts()
+    et = m.LagrangeElementType[et_name]
+    xi, wf = m.get_quadrature_volume(et)
+    _, d1, d2 = m.get_local_basis_volume(et, xi)
+    n_int = el.shape[1] * wf.size
+    K, B, w, iD, jD, D = m.get_elastic_stiffness_matrix(el, co, G * np.ones(n_int), Kb * np.ones(n_int), d1, d2, wf)
+    Q = np.ones(co.shape, dtype=bool)                                        # TSX:1695-1699
+    Q[0, co[0] < -49.99] = 0; Q[0, co[0] > 49.99] = 0
+    Q[1, co[1] < -49.99] = 0; Q[1, co[1] > 49.99] = 0
+    return K, B, w.flatten(order='F'), iD, jD, D, Q, n_int
+
+
+def _tsx_replay(m, K, B, w, iD, jD, D, Q, n_int, co, progress=None):
+    """Replay of TSX:1729-1832 (the shipped driver breaks at TSX:1677 on NumPy>=1.24 and create_midpoints
+    returns None for P1 - SURVEY C11) calling the reference's own functions, dense solves as the reference."""
+    import scipy.sparse as ssp
+    G, Kb, eta0, c0, s0, e_init = _tsx_consts()
+    n_n = co.shape[1]
+    sh = G * np.ones(n_int); bu = Kb * np.ones(n_int)
+    eta = eta0 * np.ones(n_int); c = c0 * np.ones(n_int)
+    d_zeta = 1 / 17; d_zeta_min = d_zeta / 10; d_zeta_old = d_zeta; zeta_old = 0
+    F0 = (B.T @ np.reshape(np.tile(w, (3, 1)) * s0[0:3, :], (3 * n_int, 1), order='F')).reshape((2, -1), order='F')
+    qf = Q.flatten(order='F')
+    Kd = K.toarray()
+    Kqq = Kd[np.ix_(qf, qf)]
+    del Kd
+    U_el = np.zeros((2, n_n))
+    U_el.T[Q.T] = np.linalg.solve(Kqq, -F0.T[Q.T])
+    del Kqq
+    U_it = d_zeta * U_el
+    dU = np.zeros((2, n_n)); U = np.zeros((2, n_n)); U_old = -U_it
+    Ep_old = np.zeros((4, n_int))
+    hist = []; nplast = []; Us = []; calls = 0
+    while True:
+        zeta = zeta_old + d_zeta
+        E0 = zeta * e_init
+        for it in range(25):
+            E = (B @ U_it.reshape((-1, 1), order='F')).reshape((3, -1), order='F')
+            cp = m.construct_constitutive_problem(E, E0, Ep_old, sh, bu, eta, c)
+            calls += 1
+            vD = np.tile(w, (9, 1)) * cp['ds']
+            D_p = ssp.csr_matrix((m.flatten_row(vD)[0], (m.flatten_row(iD)[0] - 1, m.flatten_row(jD)[0] - 1)),
+                                 shape=(3 * n_int, 3 * n_int))
+            K_t = K + B.T * (D_p - D) * B
+            F = (B.T @ (np.tile(w, (3, 1)) * cp['s'][0:3, :]).reshape((3 * n_int, 1), order='F')).reshape((2, n_n), order='F')
+            Ktq = K_t.tocsr()[qf][:, qf].toarray()
+            dU.T[Q.T] = np.linalg.solve(Ktq, -F.T[Q.T])
+            del Ktq
+            U_new = U_it + dU
+            a, b, cc = dU.flatten(order='F'), U_it.flatten(order='F'), U_new.flatten(order='F')
+            crit = np.sqrt(a @ K @ a) / (np.sqrt(b @ K @ b) + np.sqrt(cc @ K @ cc))
+            if np.isnan(crit):
+                break
+            U_it = U_new
+            if crit < 1e-12:
+                break
+        if crit < 1e-10:
+            U_old = U; U = U_it
+            E = (B @ U.flatten(order='F')).reshape((3, -1), order='F')
+            cp = m.construct_constitutive_problem(E, E0, Ep_old, sh, bu, eta, c)   # accept stays False: C7
+            calls += 1
+            Ep_old = cp['ep']
+            zeta_old = zeta; d_zeta_old = d_zeta
+            hist.append(zeta); nplast.append(int(np.sum(cp['ind_p']))); Us.append(U.copy())
+            if progress:
+                progress(f'    step {len(hist)} zeta={zeta:.4f} n_plast={nplast[-1]} calls={calls}')
+        else:
+            d_zeta = d_zeta / 2
+        U_it = d_zeta * (U - U_old) / d_zeta_old + U
+        if zeta_old >= 1 or d_zeta < d_zeta_min:
+            break
+    return np.array(hist), np.array(nplast), np.array(Us), F0, calls
 
 
 def gen_tsx(R):
@@ -322,93 +452,21 @@ def gen_tsx(R):
     p4 = m.create_midpoints_P4(coord, elem)
     arrs.update(p2_coord=p2['coord_ext'], p2_elem=p2['elem_ext'].astype(np.int64),
                 p4_coord=p4['coord_ext'], p4_elem=p4['elem_ext'].astype(np.int64))
-
-    young, nu = 60000, 0.2                                                       # TSX:1663-1672
-    G = young / (2 * (1 + nu)); Kb = young / (3 * (1 - 2 * nu))
-    fr = 49 * np.pi / 180
-    eta0 = 3 * np.tan(fr) / np.sqrt(9 + 12 * np.tan(fr) ** 2)
-    c0 = 3 * 18.7 / np.sqrt(9 + 12 * np.tan(fr) ** 2)
-    s0 = np.array([-45.0, -11.0, 0.0, -60.0]).reshape((-1, 1))                   # TSX:1675
-    tr0 = s0[0] + s0[1] + s0[3]
-    e_init = np.array([-nu * tr0 + (1 + nu) * s0[0], -nu * tr0 + (1 + nu) * s0[1], [0.0],
-                       -nu * tr0 + (1 + nu) * s0[3]], dtype=float).reshape((-1, 1)) / young   # TSX:1677-1681
+    G, Kb, eta0, c0, s0, e_init = _tsx_consts()
     arrs['init_strain'] = e_init
 
-    def setup(et_name, co, el):
-        et = m.LagrangeElementType[et_name]
-        xi, wf = m.get_quadrature_volume(et)
-        _, d1, d2 = m.get_local_basis_volume(et, xi)
-        n_int = el.shape[1] * wf.size
-        K, B, w, iD, jD, D = m.get_elastic_stiffness_matrix(el, co, G * np.ones(n_int), Kb * np.ones(n_int), d1, d2, wf)
-        Q = np.ones(co.shape, dtype=bool)                                        # TSX:1695-1699
-        Q[0, co[0] < -49.99] = 0; Q[0, co[0] > 49.99] = 0
-        Q[1, co[1] < -49.99] = 0; Q[1, co[1] > 49.99] = 0
-        return K, B, w.flatten(order='F'), iD, jD, D, Q, n_int
-
     # P1: elastic tangent on the free DOFs (what k_tangent_qq.csv dumps) and the full replay
-    K, B, w, iD, jD, D, Q, n_int = setup('P1', coord, elem)
+    K, B, w, iD, jD, D, Q, n_int = _tsx_setup(m, 'P1', coord, elem)
     qf = Q.flatten(order='F')
     Kqq = K.tocsr()[qf][:, qf].tocoo()
     arrs.update(p1_Kqq_row=Kqq.row.astype(np.int64), p1_Kqq_col=Kqq.col.astype(np.int64), p1_Kqq_val=Kqq.data)
 
-    # replay of TSX:1729-1832 for P1 (the shipped driver breaks at TSX:1677 on NumPy>=1.24
-    # and create_midpoints returns None for P1 - SURVEY C11) calling the reference's own functions
-    def replay(K, B, w, iD, jD, D, Q, n_int, co):
-        n_n = co.shape[1]
-        sh = G * np.ones(n_int); bu = Kb * np.ones(n_int)
-        eta = eta0 * np.ones(n_int); c = c0 * np.ones(n_int)
-        d_zeta = 1 / 17; d_zeta_min = d_zeta / 10; d_zeta_old = d_zeta; zeta_old = 0
-        F0 = (B.T @ np.reshape(np.tile(w, (3, 1)) * s0[0:3, :], (3 * n_int, 1), order='F')).reshape((2, -1), order='F')
-        qf = Q.flatten(order='F')
-        Kd = K.toarray()
-        Kqq = Kd[np.ix_(qf, qf)]
-        U_el = np.zeros((2, n_n))
-        U_el.T[Q.T] = np.linalg.solve(Kqq, -F0.T[Q.T])
-        U_it = d_zeta * U_el
-        dU = np.zeros((2, n_n)); U = np.zeros((2, n_n)); U_old = -U_it
-        Ep_old = np.zeros((4, n_int))
-        hist = []; nplast = []; Us = []
-        while True:
-            zeta = zeta_old + d_zeta
-            E0 = zeta * e_init
-            for it in range(25):
-                E = (B @ U_it.reshape((-1, 1), order='F')).reshape((3, -1), order='F')
-                cp = m.construct_constitutive_problem(E, E0, Ep_old, sh, bu, eta, c)
-                vD = np.tile(w, (9, 1)) * cp['ds']
-                D_p = ssp.csr_matrix((m.flatten_row(vD)[0], (m.flatten_row(iD)[0] - 1, m.flatten_row(jD)[0] - 1)),
-                                     shape=(3 * n_int, 3 * n_int))
-                K_t = K + B.T * (D_p - D) * B
-                F = (B.T @ (np.tile(w, (3, 1)) * cp['s'][0:3, :]).reshape((3 * n_int, 1), order='F')).reshape((2, n_n), order='F')
-                Ktq = K_t.toarray()[np.ix_(qf, qf)]
-                dU.T[Q.T] = np.linalg.solve(Ktq, -F.T[Q.T])
-                U_new = U_it + dU
-                a, b, cc = dU.flatten(order='F'), U_it.flatten(order='F'), U_new.flatten(order='F')
-                crit = np.sqrt(a @ K @ a) / (np.sqrt(b @ K @ b) + np.sqrt(cc @ K @ cc))
-                if np.isnan(crit):
-                    break
-                U_it = U_new
-                if crit < 1e-12:
-                    break
-            if crit < 1e-10:
-                U_old = U; U = U_it
-                E = (B @ U.flatten(order='F')).reshape((3, -1), order='F')
-                cp = m.construct_constitutive_problem(E, E0, Ep_old, sh, bu, eta, c)   # accept stays False: C7
-                Ep_old = cp['ep']
-                zeta_old = zeta; d_zeta_old = d_zeta
-                hist.append(zeta); nplast.append(int(np.sum(cp['ind_p']))); Us.append(U.copy())
-            else:
-                d_zeta = d_zeta / 2
-            U_it = d_zeta * (U - U_old) / d_zeta_old + U
-            if zeta_old >= 1 or d_zeta < d_zeta_min:
-                break
-        return np.array(hist), np.array(nplast), np.array(Us), F0
-
-    hist, nplast, Us, F0 = replay(K, B, w, iD, jD, D, Q, n_int, coord)
+    hist, nplast, Us, F0, _ = _tsx_replay(m, K, B, w, iD, jD, D, Q, n_int, coord)
     print('  tsx P1 replay: steps', len(hist), 'n_plast', nplast.tolist(), 'U[0,40]', Us[-1][0, 40])
     arrs.update(p1_zeta=hist, p1_nplast=nplast, p1_U_final=Us[-1], p1_U_step13=Us[12], p1_F0=F0)
 
     # P2: initial-stress load on the free DOFs (what f0q.csv dumps), TSX:1737
-    K2, B2, w2, iD2, jD2, D2, Q2, n_int2 = setup('P2', p2['coord_ext'], p2['elem_ext'])
+    K2, B2, w2, iD2, jD2, D2, Q2, n_int2 = _tsx_setup(m, 'P2', p2['coord_ext'], p2['elem_ext'])
     F0_2 = (B2.T @ np.reshape(np.tile(w2, (3, 1)) * s0[0:3, :], (3 * n_int2, 1), order='F')).reshape((2, -1), order='F')
     arrs['p2_F0'] = F0_2
     arrs['p2_Q'] = Q2
@@ -416,12 +474,33 @@ def gen_tsx(R):
     arrs['p2_K_diag'] = K2c.diagonal()
     arrs['p2_K_frob'] = np.array(np.sqrt((K2c.data ** 2).sum()))
     # P4 elastic K scalars (30x30 element matrices, 12-pt rule with the C8 typo)
-    K4, B4, w4, *_ = setup('P4', p4['coord_ext'], p4['elem_ext'])
+    K4, B4, w4, *_ = _tsx_setup(m, 'P4', p4['coord_ext'], p4['elem_ext'])
     K4c = K4.tocsr()
     arrs['p4_K_diag'] = K4c.diagonal()
     arrs['p4_K_frob'] = np.array(np.sqrt((K4c.data ** 2).sum()))
     arrs['p4_weight_sum'] = np.array(w4.sum())
     save('tsx', **arrs)
+
+
+def gen_tsx_p2p4(R, types=('P2', 'P4')):
+    """The TSX load-step sequence on the element types the reference's own demo runs (tsx-tunnel/sandbox.py:3-4:
+    P4; the driver only works for P2 / P4, TSX:1629-1633): 17 steps, dense solves on the free DOFs as the
+    reference does (P4: 14 288 free DOFs).  The meshes are the ones stored in tsx.npz (p2_*/p4_*)."""
+    m = R['tsx']
+    d = os.path.join(REF, 'tsx-tunnel')
+    coord = np.genfromtxt(os.path.join(d, 'coord.csv'), delimiter=',')
+    elem = np.genfromtxt(os.path.join(d, 'elem.csv'), delimiter=',', dtype=int) - 1
+    for t in types:
+        t0 = time.time()
+        ext = m.create_midpoints_P2(coord, elem) if t == 'P2' else m.create_midpoints_P4(coord, elem)
+        co, el = ext['coord_ext'], ext['elem_ext']
+        K, B, w, iD, jD, D, Q, n_int = _tsx_setup(m, t, co, el)
+        hist, nplast, Us, F0, calls = _tsx_replay(m, K, B, w, iD, jD, D, Q, n_int, co, progress=print)
+        print(f'  tsx {t} replay: {time.time() - t0:.0f}s steps {len(hist)} calls {calls} n_plast {nplast.tolist()} '
+              f'U[0,40] {Us[-1][0, 40]!r}')
+        keep = sorted(set([0, 1, 2, len(Us) - 3, len(Us) - 2, len(Us) - 1]))
+        save(f'tsx_{t.lower()}_trace', zeta=hist, nplast=nplast, n_calls=np.array(calls),
+             U_steps=Us[keep], steps=np.array(keep), U_mon=Us[:, 0, 40], F0=F0)
 
 
 def gen_el(R):
@@ -452,7 +531,8 @@ def gen_el(R):
 
 if __name__ == '__main__':
     R = _load_reference()
-    which = sys.argv[1:] or ['tables', 'mesh_dp', 'setup', 'retmap', 'hotpath', 'dp_trace', 'tsx', 'el']
+    which = sys.argv[1:] or ['tables', 'mesh_dp', 'setup', 'retmap', 'hotpath', 'dp_trace', 'tsx', 'el', 'transform',
+                             'dp_trace_types', 'tsx_p2p4']
     for w in which:
         print('==', w)
         globals()['gen_' + w](R)

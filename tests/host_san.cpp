@@ -1,0 +1,95 @@
+// Host-only driver of fem-elastoplasticity_amd/csrc/fep_host.h for the sanitizer builds
+// (tests/test_host_sanitizers.py: g++ -fsanitize=address,undefined and -fsanitize=thread; CPU only, no HIP).
+//   host_san MESHFILE [max_segs]
+// MESHFILE: int32 n_p, n_e, n_n, then elements (n_p x n_e, C order).  Runs the symbolic phase (threaded), the COO
+// tiles, the P1 plans with every table option (validated against the mesh), the opt-in node plan of P2/Q1/Q2 and
+// the multigrid aggregation on the node graph; prints one summary line per plan; exit code 0 = all consistent.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../fem-elastoplasticity_amd/csrc/fep_host.h"
+
+using namespace fep_host;
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t hdr[3];
+    if (std::fread(hdr, sizeof(int32_t), 3, f) != 3) return 2;
+    const int n_p = hdr[0];
+    const int64_t n_e = hdr[1], n_n = hdr[2];
+    std::vector<int32_t> elem((size_t)n_p * n_e);
+    if (std::fread(elem.data(), sizeof(int32_t), elem.size(), f) != elem.size()) return 2;
+    std::fclose(f);
+    const int max_segs = argc > 2 ? std::atoi(argv[2]) : 2;
+    Symbolic S;
+    int r = build_symbolic(n_p, n_e, n_n, elem.data(), S);
+    if (r != FEP_OK) { std::printf("build_symbolic: %d\n", r); return 1; }
+    const int64_t n_blk = (int64_t)S.ncol.size();
+    std::printf("symbolic: n_p %d n_e %lld n_n %lld blocks %lld contributions %zu\n", n_p, (long long)n_e, (long long)n_n,
+                (long long)n_blk, S.perm.size());
+    // pattern invariants: every block of node n lists n's neighbours in ascending order, one diagonal per node with elements
+    for (int64_t n = 0; n < n_n; ++n) {
+        int diag = 0;
+        for (int32_t b = S.nptr[n]; b < S.nptr[n + 1]; ++b) {
+            if (b > S.nptr[n] && S.ncol[b] <= S.ncol[b - 1]) return 1;
+            if ((S.meta[b] >> 15) & 1u) { ++diag; if (S.ncol[b] != n) return 1; }
+            if ((int)(S.meta[b] & 0x7fffu) != b - S.nptr[n] || (int)(S.meta[b] >> 16) != S.nptr[n + 1] - S.nptr[n]) return 1;
+        }
+        if (diag != (S.nptr[n + 1] > S.nptr[n] ? 1 : 0)) return 1;
+    }
+    std::vector<int32_t> tstart;
+    r = row_tiles(S, n_n, 256, tstart);
+    if (r != FEP_OK || tstart.front() != 0 || tstart.back() != n_blk) return 1;
+    for (size_t i = 1; i < tstart.size(); ++i)
+        if (tstart[i] - tstart[i - 1] > 256 || tstart[i] < tstart[i - 1]) return 1;
+    int rc = 0;
+    if (n_p == 3) {
+        struct Case { const char* name; bool lds, rng, pk, fused; int segs; };
+        const Case cases[] = {{"default", true, true, true, true, max_segs}, {"one segment", true, true, true, true, 1},
+                              {"lists", true, false, true, true, max_segs}, {"unpacked", true, true, false, true, max_segs},
+                              {"two kernels", true, true, true, false, max_segs}, {"direct", false, true, true, true, 1},
+                              {"four segments", true, true, true, true, 4}};
+        for (const Case& cs : cases) {
+            P1Options opt;
+            opt.allow_lds = cs.lds; opt.allow_rng = cs.rng; opt.allow_pk = cs.pk; opt.allow_fused = cs.fused; opt.max_segs = cs.segs;
+            P1Plan P;
+            r = build_p1_plan(S, n_e, n_n, elem.data(), opt, P);
+            const int bad = r == FEP_OK ? validate_p1_plan(P, S, n_e, n_n, elem.data()) : -1;
+            std::printf("p1 plan [%s]: rc %d check %d tiles %lld segs %d staged %lld (%.3f per element) nodes %lld L %d C %d NL %d "
+                        "lds %d rng %d pk %d fused %d/%d\n", cs.name, r, bad, (long long)P.n_wg, P.n_segs, (long long)P.staged_total,
+                        (double)P.staged_total / (double)n_e, (long long)P.staged_nodes_total, P.L, P.C, P.NL, (int)P.lds,
+                        (int)P.rng, (int)P.pk, (int)P.fused, (int)P.fused_rng);
+            if (r != FEP_OK || bad) rc = 1;
+        }
+    } else {
+        const int n_q = n_p == 6 ? 7 : n_p == 4 ? 4 : n_p == 8 ? 9 : 12;
+        GnPlan G;
+        build_gn_plan(S, n_p, n_q, n_e, G);
+        std::printf("node plan: ok %d tile %d L %d C %d lds %zu\n", (int)G.ok, G.tile, G.L, G.C, G.lds);
+        if (G.ok) {
+            const int64_t n_wg = (n_blk + G.tile - 1) / G.tile;
+            if ((int64_t)G.elist_pad.size() != n_wg * G.L || (int64_t)G.codes_pad.size() != n_wg * G.C) rc = 1;
+            for (int32_t e : G.elist_pad) if (e < 0 || e >= n_e) rc = 1;
+            for (int64_t g = 0; g < n_wg && !rc; ++g) {
+                const int64_t b0 = g * G.tile, b1 = std::min<int64_t>(n_blk, b0 + G.tile);
+                for (int32_t t = S.segptr[b0]; t < S.segptr[b1]; ++t) {
+                    const unsigned code = G.codes_pad[(size_t)(g * G.C + (t - S.segptr[b0]))];
+                    const int64_t ab = S.perm[t] / n_e, e = S.perm[t] % n_e;
+                    if ((int)(code >> 8) >= G.L || G.elist_pad[(size_t)(g * G.L + (code >> 8))] != e ||
+                        (int)((code >> 4) & 15) != ab / n_p || (int)(code & 15) != ab % n_p) rc = 1;
+                }
+            }
+        }
+    }
+    // multigrid aggregation on the node graph
+    std::vector<int32_t> agg((size_t)n_n);
+    int64_t n_agg = 0;
+    r = aggregate(n_n, S.nptr.data(), S.ncol.data(), agg.data(), &n_agg);
+    if (r != FEP_OK || n_agg <= 0 || n_agg > n_n) rc = 1;
+    for (int32_t a : agg) if (a < 0 || a >= n_agg) rc = 1;
+    std::printf("aggregate: rc %d aggregates %lld\nresult %s\n", r, (long long)n_agg, rc ? "FAILED" : "ok");
+    return rc;
+}

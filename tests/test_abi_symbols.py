@@ -32,6 +32,12 @@ def test_header_symbols_are_exported(built):
     from importlib import import_module
     proto = import_module('fem-elastoplasticity_amd._lib').PROTOTYPES
     assert sorted(proto) == names
+    # and nothing else is exported under the library's prefix: exports == header
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', built.lib_path()], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('fep_')
+                       and ln.split()[-2] in ('T', 't', 'W')})
+    assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_library_metadata_calls(built):

@@ -163,3 +163,12 @@ def test_renumber_for_locality_is_a_consistent_permutation(fep):
     K2 = orc.elastic_setup(e2, c2, sh, bu, d1, d2, wf)[0].tocsr()
     dof = (2 * node_perm[:, None] + np.arange(2)[None, :]).ravel()
     assert abs(K1[dof][:, dof] - K2).max() <= 1e-9 * abs(K1).max()
+
+
+@pytest.mark.parametrize('t', ['P1', 'P2', 'Q1', 'Q2'])
+def test_host_transform_vs_reference_golden(fep, t):
+    """The drivers' host restatement of `transform` (DP:760-816) against outputs of the reference's own function."""
+    g = load_golden('transform')
+    q, want = g[f'{t}_q_int'], g[f'{t}_q_node']
+    got = fep.transform(q, g[f'{t}_elements'], g[f'{t}_weight'])
+    assert np.abs(got - want).max() <= 1e-14 * np.abs(q).max()

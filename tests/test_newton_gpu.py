@@ -29,6 +29,61 @@ def test_dp_p1_level1_driver_vs_reference_trace(fep):
     assert relerr(h['Ep'], g['Ep_final']) <= 1e-9
 
 
+def _accepted(g):
+    """Indices of the accepted attempts of a recorded DP run: the reference logs the load factor of every ATTEMPTED
+    step (DP:1032) and, with it, the footing pressure of the last accepted one (DP:1034); after a rejected attempt the
+    next load factor is smaller (DP:1117)."""
+    z = g['zeta']
+    n_acc = g['U_accepted'].shape[0]
+    acc = [i for i in range(len(z) - 1) if z[i + 1] > z[i]]
+    if len(acc) < n_acc:
+        acc.append(len(z) - 1)
+    assert len(acc) == n_acc
+    return acc
+
+
+@pytest.mark.parametrize('t,n_steps,n_acc,n_calls,last_counts', [('Q1', 25, 24, 199, (700, 607)), ('Q2', 17, 16, 186, (986, 319)),
+                                                                  ('P2', 13, 13, 130, (1718, 725))])
+def test_dp_driver_other_element_types_vs_reference_trace(fep, t, n_steps, n_acc, n_calls, last_counts):
+    """`elasticity_fem(element_type, level=1)` of the reference (DP:901-1131) run unmodified for the element types it
+    accepts besides P1 (tests/golden/make_golden.py gen_dp_trace_types): adaptive load history incl. the rejected
+    attempts (Q1, Q2), number of return-map calls, every accepted displacement to 1e-10, pressures to 1e-9."""
+    g = load_golden(f'dp_{t.lower()}_level1_trace')
+    assert len(g['zeta']) == n_steps and g['U_accepted'].shape[0] == n_acc and int(g['n_calls']) == n_calls
+    acc = _accepted(g)
+    h = fep.solve_strip_footing(t, level=1)
+    assert len(h['zeta']) == n_acc
+    assert np.allclose(h['zeta'], g['zeta'][acc], rtol=0, atol=1e-15)           # same accepted load factors
+    # Newton stops at criterion < 1e-12 (DP:1086): an iterate that lands within rounding of that threshold takes one
+    # iteration more or less with another linear solver (SuperLU here, dense LAPACK there); same rejections otherwise
+    assert abs(h['n_calls'] - n_calls) <= 2, h['n_calls']
+    for k in range(n_acc):
+        assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-10, k
+    pmax = np.abs(g['pressure']).max()
+    for k, i in enumerate(acc):
+        if i + 1 < len(g['pressure']):
+            assert abs(h['pressure'][k] - g['pressure'][i + 1]) <= 1e-9 * pmax, k
+    assert h['counts'][-1] == tuple(g['counts'][-1]) == last_counts
+    assert relerr(h['Ep'], g['Ep_final']) <= 1e-9
+
+
+@pytest.mark.parametrize('t', ['P2', 'P4'])
+def test_tsx_driver_on_the_demo_element_types_vs_reference_replay(fep, t):
+    """The TSX load-step sequence on the element types the reference's demo runs (tsx-tunnel/sandbox.py:3-4: P4; the
+    driver only works for P2 / P4, TSX:1629-1633), against the replay recorded with the reference's own functions and
+    dense solves (make_golden.py gen_tsx_p2p4): 17 steps, plastic-point counts, call count, displacements 1e-10."""
+    g0 = load_golden('tsx')
+    g = load_golden(f'tsx_{t.lower()}_trace')
+    h = fep.solve_tsx_tunnel(g0[f'{t.lower()}_coord'], g0[f'{t.lower()}_elem'], t)
+    assert len(h['zeta']) == 17 == len(g['zeta']) and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
+    assert h['n_plast'] == g['nplast'].tolist() and h['n_plast'][-1] > 0
+    assert h['n_calls'] == int(g['n_calls'])
+    assert relerr(h['F0'], g['F0']) <= 1e-12
+    for k, step in enumerate(g['steps']):
+        assert relerr(h['U'][int(step)], g['U_steps'][k]) <= 1e-10, step
+    assert np.abs(np.array(h['displ']) - g['U_mon']).max() <= 1e-10 * np.abs(g['U_mon']).max()
+
+
 def test_tsx_p1_driver_vs_reference_replay(fep):
     g = load_golden('tsx')
     h = fep.solve_tsx_tunnel(g['coord'], g['elem'], 'P1')
@@ -68,6 +123,20 @@ def test_tsx_p4_full_run_consistent_with_p2_and_p1(fep):
     for k in el[1:]:
         assert relerr(h4['U'][k] / h4['zeta'][k], h4['U'][el[0]] / h4['zeta'][el[0]]) <= 1e-9
     assert h4['n_plast'][-1] > 0
+
+
+@pytest.mark.parametrize('t', ['P1', 'P2', 'Q1', 'Q2'])
+def test_transform_vs_reference_golden(fep, t):
+    """`transform` (DP:760-816) against outputs of the reference's own function (make_golden.py gen_transform): the
+    device kernel behind fep_transform_host and the host restatement the drivers use."""
+    g = load_golden('transform')
+    elem, coord, w, q, want = (g[f'{t}_{k}'] for k in ('elements', 'coordinates', 'weight', 'q_int', 'q_node'))
+    ctx = fep.MeshContext(elem, coord)
+    got = ctx.transform(q)
+    ctx.close()
+    tol = 1e-14 * np.abs(q).max()                # every node against the size of the averaged values (they cancel)
+    assert np.abs(got - want).max() <= tol
+    assert np.abs(fep.transform(q, elem, w) - want).max() <= tol
 
 
 def test_transform_matches_definition(fep):

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import scipy.sparse as ssp
 
-from conftest import dp_materials, load_golden, relerr
+from conftest import dp_materials, load_golden, relerr, relerr_points, relerr_rows
 from oracle import fep_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -22,6 +22,11 @@ ELS = ('P1', 'P2', 'Q1', 'Q2')
 NQ = {'P1': 1, 'P2': 7, 'Q1': 4, 'Q2': 9, 'P4': 12}
 TOL_PT = 1e-13
 TOL_K = 1e-12
+# per integration point / per matrix row (conftest.relerr_points, relerr_rows): every point against ITS OWN largest
+# entry, every row of K against its own largest entry; the stress of a smooth point is a difference of two terms of
+# the trial stress's size (DP:720), hence the extra decade
+TOL_PT_EACH = 1e-12
+TOL_K_EACH = 1e-11
 
 
 def tables(mod, t):
@@ -49,6 +54,7 @@ def test_return_map_vs_reference_golden(fep, case, order):
     assert np.array_equal(r['ind_p'], g[case + '_ind_p'])
     assert relerr(r['s'], g[case + '_s']) <= TOL_PT
     assert relerr(r['ds'], g[case + '_ds']) <= TOL_PT
+    assert relerr_points(r['s'], g[case + '_s']) <= TOL_PT_EACH and relerr_points(r['ds'], g[case + '_ds']) <= TOL_PT_EACH
     if accept:
         assert relerr(r['ep'], g[case + '_ep']) <= TOL_PT
         assert r['ep'] is ep_in                                        # C4 aliasing
@@ -143,9 +149,11 @@ def test_elastic_setup_vs_reference_golden(fep, t):
 
 
 # ---- a1..a5 ---------------------------------------------------------------------------
-@pytest.fixture(params=['node', 'node_unpacked', 'node_list', 'node_direct', 'coo'])
+@pytest.fixture(params=['node', 'node2k', 'node_unpacked', 'node_list', 'node_direct', 'coo'])
 def p1_route(request, monkeypatch):
-    """P1 has two routes: the node-centric fast path (default) and the generic COO route."""
+    """P1 routes: the node-centric fast path (default: one fused kernel per non-accepting step, two kernels otherwise;
+    'node2k' = always two kernels; the other node_* names switch off one table compression each) and the generic COO
+    route."""
     monkeypatch.setenv('FEP_P1_PATH', request.param)
     return request.param
 
@@ -154,6 +162,99 @@ def test_p1_routes_agree_and_match_reference(fep, p1_route):
     test_hot_path_vs_reference_golden(fep, 'P1', True)
     test_hot_path_vs_reference_golden(fep, 'P1', False)
     test_hot_path_mid_size_vs_oracle(fep, 'P1', 60)
+
+
+def _p1_case(fep, name):
+    rng = np.random.default_rng(12)
+    if name in ('rows', 'random'):
+        from scipy.spatial import Delaunay
+        M = 40
+        g = np.stack(np.meshgrid(np.arange(M + 1), np.arange(M + 1), indexing='xy')).reshape(2, -1).astype(float)
+        inner = (g[0] > 0) & (g[0] < M) & (g[1] > 0) & (g[1] < M)
+        g[:, inner] += rng.uniform(-0.35, 0.35, size=(2, int(inner.sum())))
+        coord = g * (10.0 / M)
+        if name == 'random':
+            coord = coord[:, rng.permutation(coord.shape[1])]
+        elem = Delaunay(coord.T).simplices.T.astype(np.int64)
+        if name == 'random':
+            elem = elem[:, rng.permutation(elem.shape[1])]
+    else:
+        N = {'square150': 150, 'square7': 7, 'hetero': 90, 'tsx': 64}[name]
+        mesh = fep.square_mesh(N, 'P1', 10)
+        elem, coord = mesh['elements'], mesh['coordinates'].copy()
+        inner = np.logical_and.reduce([coord[0] > 0, coord[0] < 10, coord[1] > 0, coord[1] < 10])
+        coord[:, inner] += rng.uniform(-0.1, 0.1, size=(2, inner.sum())) * (10 / N)
+    n = elem.shape[1]
+    mats = dp_materials(n)
+    if name == 'hetero':
+        mats = [v * rng.uniform(0.8, 1.25, n) for v in mats]
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    U += rng.normal(0, 3e-6, size=U.shape)
+    Ep = rng.normal(0, 5e-6, size=(4, n))
+    e0 = np.array([-3e-5, 2e-5, 0.0, -4e-5]) if name == 'tsx' else None
+    return elem, coord, mats, U, Ep, e0
+
+
+@pytest.mark.parametrize('name', ['square150', 'square7', 'hetero', 'tsx', 'rows', 'random'])
+def test_p1_fused_step_is_bitwise_the_two_kernel_route(fep, monkeypatch, name):
+    """A non-accepting P1 step runs as ONE kernel (return map inside the assembly kernel's staging phase, s / ds never
+    in HBM unless asked for).  Bit for bit the two-kernel route: K, F with and without the point outputs, s, ds, ind_p,
+    strain, counters — structured and Delaunay meshes (run-compressed and list tables), per-point materials, e0."""
+    elem, coord, mats, U, Ep, e0 = _p1_case(fep, name)
+    res = {}
+    for route in ('node', 'node2k'):
+        monkeypatch.setenv('FEP_P1_PATH', route)
+        ctx = fep.MeshContext(elem, coord)
+        ctx.set_materials(*mats)
+        ep = Ep.copy()
+        kw = {} if e0 is None else {'e0': e0}
+        full = ctx.step(U, ep, want=('E', 's', 'ds', 'ind_p', 'K', 'F'), **kw)
+        kf = ctx.step(U, ep, want=('K', 'F'), **kw)
+        k_only = ctx.step(U, ep, want=('K',), **kw)
+        f_only = ctx.step(U, None, want=('F',), **kw)
+        assert np.array_equal(ep, Ep)
+        res[route] = (full, kf, k_only, f_only)
+        ctx.close()
+    a, b = res['node'], res['node2k']
+    assert a[0]['n_smooth'] > 0 and a[0]['n_apex'] > 0
+    for x, y in zip(a, b):
+        assert (x['n_smooth'], x['n_apex']) == (y['n_smooth'], y['n_apex'])
+        for key in x:
+            if key == 'K':
+                assert np.array_equal(x['K'].data, y['K'].data), key
+            elif key not in ('n_smooth', 'n_apex'):
+                assert np.array_equal(x[key], y[key]), key
+    assert np.array_equal(a[0]['K'].data, a[1]['K'].data) and np.array_equal(a[0]['F'], a[1]['F'])
+    assert np.array_equal(a[0]['K'].data, a[2]['K'].data)
+
+
+def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
+    """A node that belongs to no element has no block in K and no lane that writes its force: F must still come back
+    as zero there on every route (the reference's B^T product gives 0), not as uninitialised memory."""
+    mesh = fep.square_mesh(12, 'P1', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n_n = coord.shape[1]
+    coord = np.concatenate([coord[:, :50], [[3.3], [4.4]], coord[:, 50:], [[20.0], [20.0]]], axis=1)   # orphans: id 50 and the last
+    elem = np.where(elem >= 50, elem + 1, elem)
+    n = elem.shape[1]
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(*dp_materials(n))
+    F_poison = ctx.step(1e3 * U, None, want=('F',))['F']                       # leaves other values in freed device memory
+    r = ctx.step(U, np.zeros((4, n)), want=('s', 'ds', 'K', 'F'))
+    assert r['F'][2 * 50] == 0 and r['F'][2 * 50 + 1] == 0 and r['F'][-1] == 0 and r['F'][-2] == 0
+    d1, d2, wf = fep.element_tables('P1')
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, *dp_materials(n)[:2], d1, d2, wf)
+    sh, bu, eta, c = dp_materials(n)
+    E, cp, K_t, F = orc.hot_path(U, np.zeros((4, n)), dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=sh,
+                                                          bulk=bu, eta=eta, c=c))
+    assert relerr(r['F'], F) <= TOL_K and np.abs((r['K'] - K_t).data).max() <= TOL_K * np.abs(K_t.data).max()
+    assert r['K'].shape == (2 * (n_n + 2), 2 * (n_n + 2))
+    K2, F2 = ctx.assemble(r['ds'], r['s'])
+    assert np.array_equal(F2, r['F'])
+    ctx.close()
 
 
 @pytest.fixture(params=['node', 'coo'])
@@ -186,7 +287,9 @@ def test_hot_path_vs_reference_golden(fep, t, accept):
     assert relerr(r['E'], g[tag + 'E']) <= 1e-14
     assert np.array_equal(r['ind_p'], g[tag + 'ind_p'])
     assert relerr(r['s'], g[tag + 's']) <= TOL_PT and relerr(r['ds'], g[tag + 'ds']) <= TOL_PT
+    assert relerr_points(r['s'], g[tag + 's']) <= TOL_PT_EACH and relerr_points(r['ds'], g[tag + 'ds']) <= TOL_PT_EACH
     assert relerr(r['K'].toarray(), g[tag + 'K_t']) <= TOL_K
+    assert relerr_rows(r['K'].toarray(), g[tag + 'K_t']) <= TOL_K_EACH
     assert relerr(r['F'], g[tag + 'F']) <= TOL_K
     if accept:
         assert relerr(ep, g[tag + 'ep']) <= TOL_PT
@@ -322,8 +425,10 @@ def test_hot_path_mid_size_vs_oracle(fep, t, N, heterogeneous=False):
     assert np.array_equal(r['ind_p'], cp['ind_p'])
     assert relerr(r['E'], E) <= 1e-13
     assert relerr(r['s'], cp['s']) <= TOL_PT and relerr(r['ds'], cp['ds']) <= TOL_PT and relerr(ep, ep_o) <= TOL_PT
+    assert relerr_points(r['s'], cp['s']) <= TOL_PT_EACH and relerr_points(r['ds'], cp['ds']) <= TOL_PT_EACH
     diff = (r['K'] - K_t)
     assert np.abs(diff.data).max() <= TOL_K * np.abs(K_t.data).max()
+    assert relerr_rows(r['K'], K_t) <= TOL_K_EACH
     assert relerr(r['F'], F) <= TOL_K
 
 

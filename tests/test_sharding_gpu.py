@@ -2,6 +2,8 @@
 the other on cuda:0, the interface forces are summed the way the all-reduce does, and everything is compared
 with the single-context result on the global mesh.  (The multi-process exchange itself is covered on CPU by
 tests/test_sharding_gloo.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,3 +127,53 @@ def test_contexts_and_solvers_release_their_device_memory(fep):
         cycle()
     torch.cuda.empty_cache()
     assert used() - base <= 64 << 20         # allocator granularity, not a per-cycle leak (five cycles allocate ~0.5 GB)
+
+
+@pytest.mark.parametrize('t,world', [('P1', 2), ('Q1', 2)])
+def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
+    """The product's multi-GPU path with real processes: `world` fresh processes share cuda:0 (gloo rendezvous), each
+    runs ShardedContext.step_dev + exchange_force_ (pack kernel -> all-reduce -> unpack kernel) on two streams with a
+    double-buffered force vector — the sequence bench.py --gpus N drives (tests/shard_worker.py).  After the exchange
+    every rank must hold the single-context force on ALL its local DOFs, in both buffers, and the sub-assembled K_r
+    must sum to the global K."""
+    import socket
+    import subprocess
+    import sys
+    import scipy.sparse as ssp
+    import shard_worker as sw
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shard_worker.py')
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path), t], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    # the single-context result, meanwhile, in this process
+    elem, coord, U = sw.problem(fep, t)
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(*sw.materials())
+    ref = ctx.step(U, np.zeros((4, ctx.n_int)), want=('K', 'F'))
+    assert ref['n_smooth'] > 0 and ref['n_apex'] > 0
+    n_dof = ctx.n_dof
+    ctx.close()
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+    fmax = np.abs(ref['F']).max()
+    K_sum, counts, covered = None, np.zeros(2, dtype=np.int64), np.zeros(n_dof // 2, dtype=int)
+    for r in range(world):
+        d = np.load(tmp_path / f'rank{r}.npz')
+        dofs = (2 * d['nodes'][:, None] + np.arange(2)[None, :]).ravel()
+        for key in ('F0', 'F1'):
+            assert np.isfinite(d[key]).all()
+            assert np.abs(d[key] - ref['F'][dofs]).max() <= 1e-12 * fmax, (r, key)
+        Kr = ssp.csr_matrix((d['k_data'], d['indices'], d['indptr']), shape=(dofs.size, dofs.size)).tocoo()
+        Kg = ssp.coo_matrix((Kr.data, (dofs[Kr.row], dofs[Kr.col])), shape=(n_dof, n_dof)).tocsr()
+        K_sum = Kg if K_sum is None else K_sum + Kg
+        counts += d['counts']
+        covered[d['nodes']] += 1
+        assert int(d['n_iface']) == (covered > 1).sum() or r == 0
+    assert (covered >= 1).all() and (covered > 1).sum() == 41 * (world - 1)       # one node row per cut
+    assert tuple(counts) == (ref['n_smooth'], ref['n_apex'])
+    assert np.abs((K_sum - ref['K']).data).max() <= 1e-12 * np.abs(ref['K'].data).max()
