@@ -46,7 +46,7 @@ struct fep_ctx {
     int n_wg_p1 = 0;   // LDS-staged variant: per-workgroup element lists
     // one-kernel step (p1_fused_kernel): per-tile node lists / runs, per staged element its tile-local node indices + owner bit
     bool p1_fused = false, p1_fused_rng = false;
-    int fused_mode = 2;                                 // FEP_P1_FUSED: 0 = never, 1 = only when no point output is wanted, 2 = always
+    int fused_mode = 1;                                 // FEP_P1_FUSED=off|kf|all: 0 = never, 1 = only when no point output is wanted (default), 2 = always
     int lds_NL = 0;                                     // staged nodes per tile (max)
     int32_t *wg_nlist = nullptr, *wg_nrng = nullptr;
     uint32_t* el_nodes = nullptr;

@@ -159,8 +159,8 @@ inline int row_tiles(const Symbolic& S, int64_t n_n, int tile, std::vector<int32
 // still writes its CSR values / forces as one contiguous range PER SEGMENT.  Which tiling is used is decided by
 // counting: the multi-segment one must stage at least 5 % fewer elements over the whole mesh.
 //
-//   tdesc  kDescInts int32 per tile: [pk_base, n_blocks, n_nodes, n_segments] then kSegMax x
-//          [first_block, n_blocks, first_node, n_nodes]  (scalar loads in the kernels)
+//   tdesc  kDescInts int32 per tile: [pk_base, n_blocks, n_nodes, n_segments | staged elements << 4 | staged nodes << 16]
+//          then kSegMax x [first_block, n_blocks, first_node, n_nodes]  (scalar loads in the kernels)
 //   elist_pad / rng_tab   sorted unique elements of the tile, padded to L with its first element / as <= 8 runs
 //   codes_pad             gather codes (local element << 4 | a << 2 | b) in tile block order, padded to C
 //   pkv                   per lane of the tile (lanes sorted by descending segment length) the packed descriptor
@@ -174,6 +174,7 @@ constexpr int kDescInts = 4 * (1 + kSegMax);
 struct P1Options {
     int tile = 256;
     int max_segs = 2;
+    int staged_cap = 128;                    // multi-segment tiles that would stage more elements are split into their segments
     bool allow_lds = true, allow_rng = true, allow_pk = true, allow_fused = true;
 };
 
@@ -197,16 +198,20 @@ inline int make_tiles(const Symbolic& S, int64_t n_n, int tile, int max_segs, st
     max_segs = std::max(1, std::min(max_segs, kSegMax));
     std::vector<uint8_t> assigned((size_t)n_n, 0);
     for (int64_t n = 0; n < n_n; ++n) assigned[n] = S.nptr[n + 1] == S.nptr[n];      // nodes of no element: no blocks, no tile
-    const int seg_budget = tile / max_segs;
     std::vector<int32_t> nbrs;
     int64_t p = 0;
     while (true) {
         while (p < n_n && assigned[p]) ++p;
         if (p >= n_n) break;
         Tile t;
-        int total_nodes = 0;
+        int total_nodes = 0, total_blocks = 0;
         int64_t start = p;
         for (int s = 0; s < max_segs; ++s) {
+            // an even share of what is left of the tile: the first segment takes tile / max_segs blocks, the last one
+            // whatever the others left, so that tiles come out full (their number sets the kernels' time)
+            // (but no segment much longer than its even share: a long one stages as much as a whole row strip)
+            const int seg_budget = std::min((tile - total_blocks + (max_segs - s) - 1) / (max_segs - s),
+                                            max_segs > 1 ? tile / max_segs + 8 : tile);
             int64_t n = start;
             int blocks = 0;
             while (n < n_n && !assigned[n] && blocks + (S.nptr[n + 1] - S.nptr[n]) <= seg_budget && total_nodes + (int)(n - start) < 255) {
@@ -222,9 +227,10 @@ inline int make_tiles(const Symbolic& S, int64_t n_n, int tile, int max_segs, st
             t.fb[s] = S.nptr[start]; t.nb[s] = blocks; t.fn[s] = (int32_t)start; t.nn[s] = (int32_t)(n - start);
             t.nseg = s + 1;
             total_nodes += (int)(n - start);
+            total_blocks += blocks;
             for (int64_t m = start; m < n; ++m) assigned[m] = 1;
-            if (s + 1 == max_segs || blocks > seg_budget) break;
-            // next segment: the longest run of consecutive unassigned neighbour ids of this one
+            if (s + 1 == max_segs || total_blocks >= tile) break;
+            // next segment: the longest run of consecutive unassigned neighbour ids of this one ...
             nbrs.clear();
             for (int32_t b = S.nptr[start]; b < S.nptr[n]; ++b)
                 if (!assigned[S.ncol[b]]) nbrs.push_back(S.ncol[b]);
@@ -238,7 +244,15 @@ inline int make_tiles(const Symbolic& S, int64_t n_n, int tile, int max_segs, st
                 i = j;
             }
             if (best_len < 2) break;
+            // ... started below it when that closes a short gap (what the previous tile's segment left of that row;
+            // such leftovers would otherwise make small tiles of their own); never walks into untouched territory
             start = nbrs[best];
+            {
+                int64_t lo = start;
+                int gap = 0;
+                while (lo > 0 && !assigned[lo - 1] && gap < 32) { --lo; ++gap; }
+                if (gap < 32) start = lo;
+            }
         }
         tiles.push_back(t);
     }
@@ -274,6 +288,35 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
     std::vector<Tile> tiles;
     const int r = make_tiles(S, n_n, TILE, max_segs, tiles);
     if (r != FEP_OK) return r;
+    if (max_segs > 1 && opt.staged_cap > 0) {
+        // a multi-segment tile whose segments turned out not to share elements (first rows, junctions of the brick
+        // pattern) stages as much as two tiles: make it two, so that the LDS image of EVERY tile stays small
+        std::vector<int32_t> count(tiles.size(), 0);
+        parallel_chunks((int64_t)tiles.size(), [&](int64_t lo, int64_t hi, int) {
+            std::vector<int32_t> l;
+            for (int64_t g = lo; g < hi; ++g) {
+                const Tile& t = tiles[g];
+                if (t.nseg < 2) continue;
+                l.clear();
+                for (int s = 0; s < t.nseg; ++s)
+                    for (int32_t c = S.segptr[t.fb[s]]; c < S.segptr[t.fb[s] + t.nb[s]]; ++c) l.push_back(P.perm2[c] >> 4);
+                std::sort(l.begin(), l.end());
+                count[g] = (int32_t)(std::unique(l.begin(), l.end()) - l.begin());
+            }
+        });
+        std::vector<Tile> split;
+        split.reserve(tiles.size());
+        for (size_t g = 0; g < tiles.size(); ++g) {
+            const Tile& t = tiles[g];
+            if (count[g] <= opt.staged_cap) { split.push_back(t); continue; }
+            for (int s = 0; s < t.nseg; ++s) {
+                Tile u;
+                u.nseg = 1; u.fb[0] = t.fb[s]; u.nb[0] = t.nb[s]; u.fn[0] = t.fn[s]; u.nn[0] = t.nn[s];
+                split.push_back(u);
+            }
+        }
+        tiles.swap(split);
+    }
     const int64_t n_wg = (int64_t)tiles.size();
     P.n_wg = n_wg;
     P.tdesc.assign((size_t)n_wg * kDescInts, 0);
@@ -320,6 +363,7 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
         cmax = std::max(cmax, codes[g].size());
         P.staged_total += (int64_t)lists[g].size();
     }
+    for (int64_t g = 0; g < n_wg; ++g) P.tdesc[(size_t)g * kDescInts + 3] |= (int32_t)(lists[g].size() << 4);   // staged elements of the tile
     P.C = (int)((cmax + 7) & ~(size_t)7);
     P.L = (int)((lmax + 1) & ~(size_t)1);
     // 15 doubles per staged element; the staged kernels hold <= 2 elements and <= 4 gather codes per lane in registers
@@ -434,6 +478,7 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
         std::copy(nl.begin(), nl.end(), P.nlist_pad.begin() + g * NLP);
         if (nfits) runs_of(nl, P.nrng_tab.data() + g * 16, nfits);
     }
+    for (int64_t g = 0; g < n_wg; ++g) P.tdesc[(size_t)g * kDescInts + 3] |= (int32_t)(nlists[g].size() << 16);  // staged nodes of the tile
     P.fused_rng = nfits;
     const size_t lds_f = (((size_t)P.L * 15 * sizeof(double) + (size_t)P.C * 2 + 15) & ~(size_t)15) + (size_t)NLP * 32;
     P.fused = lds_f <= 96 * 1024;
@@ -463,9 +508,10 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
     int64_t pk_base = 0;
     for (int64_t g = 0; g < P.n_wg; ++g) {
         const int32_t* d = P.tdesc.data() + g * kDescInts;
-        if (d[0] != pk_base || d[3] < 1 || d[3] > kSegMax || d[1] > P.tile || d[1] < 1 || d[2] > 255) return 2;
+        const int nseg = d[3] & 15, n_staged = (d[3] >> 4) & 4095, n_staged_nodes = (d[3] >> 16) & 4095;
+        if (d[0] != pk_base || nseg < 1 || nseg > kSegMax || d[1] > P.tile || d[1] < 1 || d[2] > 255) return 2;
         int nb = 0, nn = 0;
-        for (int s = 0; s < d[3]; ++s) {
+        for (int s = 0; s < nseg; ++s) {
             const int32_t fb = d[4 + 4 * s], sb = d[5 + 4 * s], fn = d[6 + 4 * s], sn = d[7 + 4 * s];
             if (fn < 0 || fn + sn > n_n || sn < 1 || S.nptr[fn] != fb || S.nptr[fn + sn] != fb + sb) return 3;
             for (int32_t b = fb; b < fb + sb; ++b) { if (seen[b]) return 4; seen[b] = 1; }
@@ -480,6 +526,7 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
             if (el[i] < 0 || el[i] >= n_e) return 6;
             if (i > 0 && el[i] > el[i - 1]) n_list = i + 1;
         }
+        if (n_list != n_staged) return 18;
         if (P.rng) {
             const int32_t* r = P.rng_tab.data() + g * 16;
             for (int i = 0; i < P.L; ++i) {
@@ -507,8 +554,12 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
         }
         if (P.fused) {
             const int32_t* nl = P.nlist_pad.data() + g * P.NL;
-            for (int i = 0; i < P.NL; ++i)
+            int n_nl = 1;
+            for (int i = 0; i < P.NL; ++i) {
                 if (nl[i] < 0 || nl[i] >= n_n) return 11;
+                if (i > 0 && nl[i] > nl[i - 1]) n_nl = i + 1;
+            }
+            if (n_nl != n_staged_nodes) return 19;
             if (P.fused_rng) {
                 const int32_t* r = P.nrng_tab.data() + g * 16;
                 for (int i = 0; i < P.NL; ++i) {

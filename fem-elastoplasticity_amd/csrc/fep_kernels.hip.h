@@ -666,50 +666,44 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 // has exactly one segment (its blocks are first_block + lane).
 constexpr int kSegMax = 4;
 
-struct TileDesc { int4 h, s[kSegMax]; };
+static_assert(kSegMax == 4, "the tile descriptor names its four segments");
+// plain ints (no HIP vector types, no arrays): the descriptor stays in scalar registers
+struct TileDesc {
+    int pk_base, nb, nn, nseg, n_el, n_nd;              // n_el / n_nd: staged elements / nodes of THIS tile (<= L / NL)
+    int fb0, nb0, fn0, nn0, fb1, nb1, fn1, nn1, fb2, nb2, fn2, nn2, fb3, nb3, fn3, nn3;
+};
 
 __device__ __forceinline__ TileDesc load_tile_desc(const int4* __restrict__ tdesc, int wg) {
-    const int4* d = tdesc + (int64_t)wg * (1 + kSegMax);          // uniform address: scalar loads
+    const int32_t* d = reinterpret_cast<const int32_t*>(tdesc) + (int64_t)wg * 4 * (1 + kSegMax);   // uniform address: scalar loads
     TileDesc t;
-    t.h = d[0];
-#pragma unroll
-    for (int k = 0; k < kSegMax; ++k) t.s[k] = d[1 + k];
+    t.pk_base = d[0]; t.nb = d[1]; t.nn = d[2]; t.nseg = d[3] & 15; t.n_el = (d[3] >> 4) & 4095; t.n_nd = (d[3] >> 16) & 4095;
+    t.fb0 = d[4]; t.nb0 = d[5]; t.fn0 = d[6]; t.nn0 = d[7];
+    t.fb1 = d[8]; t.nb1 = d[9]; t.fn1 = d[10]; t.nn1 = d[11];
+    t.fb2 = d[12]; t.nb2 = d[13]; t.fn2 = d[14]; t.nn2 = d[15];
+    t.fb3 = d[16]; t.nb3 = d[17]; t.fn3 = d[18]; t.nn3 = d[19];
     return t;
 }
 
 // The tile's LDS output image -> HBM: CSR values (2*nb double2 in tile block order) and forces (nn double2 in tile
 // node order), each segment to its own contiguous range.
 template <int TPB>
-__device__ __forceinline__ void store_tile_outputs(const TileDesc& t, const double2* __restrict__ out2, const double2* __restrict__ fo2,
+__device__ __forceinline__ void store_tile_outputs(const TileDesc t, const double2* __restrict__ out2, const double2* __restrict__ fo2,
                                                    double* __restrict__ data, double* __restrict__ F) {
     if (data) {
-        const int n2 = 2 * t.h.y;
+        const int n2 = 2 * t.nb;
+        const int e0 = 2 * t.nb0, e1 = e0 + 2 * t.nb1, e2 = e1 + 2 * t.nb2;          // ends of the segments' images
         for (int i = threadIdx.x; i < n2; i += TPB) {
-            int j = i, seg = 0;                                   // i < 2 * (sum of the segments' blocks)
-#pragma unroll
-            for (int k = 0; k + 1 < kSegMax; ++k) {
-                const bool adv = seg == k && j >= 2 * t.s[k].y;
-                j = adv ? j - 2 * t.s[k].y : j;
-                seg = adv ? k + 1 : seg;
-            }
-            int64_t fb = t.s[0].x;
-#pragma unroll
-            for (int k = 1; k < kSegMax; ++k) fb = seg == k ? t.s[k].x : fb;
+            const int64_t fb = i < e0 ? t.fb0 : i < e1 ? t.fb1 : i < e2 ? t.fb2 : t.fb3;
+            const int j = i < e0 ? i : i < e1 ? i - e0 : i < e2 ? i - e1 : i - e2;
             reinterpret_cast<double2*>(data + 4 * fb)[j] = out2[i];
         }
     }
-    if (F && (int)threadIdx.x < t.h.z) {
-        int j = threadIdx.x, seg = 0;
-#pragma unroll
-        for (int k = 0; k + 1 < kSegMax; ++k) {
-            const bool adv = seg == k && j >= t.s[k].w;
-            j = adv ? j - t.s[k].w : j;
-            seg = adv ? k + 1 : seg;
-        }
-        int64_t fn = t.s[0].z;
-#pragma unroll
-        for (int k = 1; k < kSegMax; ++k) fn = seg == k ? t.s[k].z : fn;
-        reinterpret_cast<double2*>(F + 2 * fn)[j] = fo2[threadIdx.x];
+    if (F && (int)threadIdx.x < t.nn) {
+        const int i = threadIdx.x;
+        const int e0 = t.nn0, e1 = e0 + t.nn1, e2 = e1 + t.nn2;
+        const int64_t fn = i < e0 ? t.fn0 : i < e1 ? t.fn1 : i < e2 ? t.fn2 : t.fn3;
+        const int j = i < e0 ? i : i < e1 ? i - e0 : i < e2 ? i - e1 : i - e2;
+        reinterpret_cast<double2*>(F + 2 * fn)[j] = fo2[i];
     }
 }
 
@@ -738,8 +732,8 @@ p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr
     // addresses are functions of (tile, lane) and go out together at kernel entry; the operand loads
     // follow as soon as the list entries land.
     const TileDesc td = load_tile_desc(tdesc, wg);
-    const int nb = td.h.y;
-    const int64_t sb = PK ? (int64_t)td.h.x + threadIdx.x : (int64_t)td.s[0].x + threadIdx.x;
+    const int nb = td.nb;
+    const int64_t sb = PK ? (int64_t)td.pk_base + threadIdx.x : (int64_t)td.fb0 + threadIdx.x;
     const bool live = (int)threadIdx.x < nb;
     constexpr int CWPT = 2;                             // 32-bit words of gather codes per lane (2 codes each;
                                                         // host guarantees C <= 2*CWPT*TPB and C even)
@@ -770,9 +764,10 @@ p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr
     // instruction count); inside a wave every lane loads (slots past the list repeat a valid element).
     double2 g0[EPT], g1[EPT], g2[EPT];                  // 48-byte geometry record (3 x 16-byte loads; the SoA dphi
     double dv[EPT][6], sv[EPT][3];                      // arrays as 7 x 8-byte loads measured 5-10 us slower)
+    const int n_el = td.n_el;                           // slots past the tile's own list stage nothing
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
-        if (r * TPB + (int)(threadIdx.x & ~63u) >= L) continue;
+        if (r * TPB + (int)(threadIdx.x & ~63u) >= n_el) continue;
         const int64_t e = el[r];
         const double2* g = reinterpret_cast<const double2*>(geo + e * 6);
         g0[r] = g[0]; g1[r] = g[1]; g2[r] = g[2];
@@ -815,7 +810,7 @@ p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
-        if (i < L) {
+        if (i < n_el) {
             const double w = g2[r].x;
             rec[9 * L + i] = g0[r].x;  rec[10 * L + i] = g0[r].y; rec[11 * L + i] = -(g0[r].x + g0[r].y);   // d1[0..2]
             rec[12 * L + i] = g1[r].x; rec[13 * L + i] = g1[r].y; rec[14 * L + i] = -(g1[r].x + g1[r].y);   // d2[0..2]
@@ -909,7 +904,7 @@ p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr
 // read an element's updated plastic strain.
 // ---------------------------------------------------------------------------------------
 template <bool FULL, int TPB, bool RNG, int EPT, int NPT>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, (!FULL && EPT == 1) ? 8 : 1)     // K/F-only: 64 VGPRs, 8 tiles of 4 waves per CU
 p1_fused_kernel(int64_t n_e, int L, int C, int NL,
                 const uint16_t* __restrict__ perm_l, const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
                 const int32_t* __restrict__ wg_nlist, const int4* __restrict__ nrng,
@@ -926,8 +921,8 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (wg >= n_wg) return;
     const TileDesc td = load_tile_desc(tdesc, wg);
-    const int nb = td.h.y;
-    const int64_t sb = (int64_t)td.h.x + threadIdx.x;                  // lane of the tile -> its packed descriptor
+    const int nb = td.nb;
+    const int64_t sb = (int64_t)td.pk_base + threadIdx.x;                  // lane of the tile -> its packed descriptor
     const bool live = (int)threadIdx.x < nb;
     constexpr int CWPT = 2;
     if (threadIdx.x == 0) { sc[0] = 0u; sc[1] = 0u; }
@@ -972,10 +967,11 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
         }
     }
     // (2) loads, all issued before the first use: node data, the slots' node words / plastic strain / materials
+    const int n_el = td.n_el, n_nd = td.n_nd;           // this tile's staged elements / nodes (<= L / NL)
     double2 nxy[NPT], nu[NPT];
 #pragma unroll
     for (int r = 0; r < NPT; ++r) {
-        if (r * TPB + (int)(threadIdx.x & ~63u) >= NL) continue;     // wave-uniform: idle waves issue nothing
+        if (r * TPB + (int)(threadIdx.x & ~63u) >= n_nd) continue;   // wave-uniform: idle waves issue nothing
         nxy[r] = *reinterpret_cast<const double2*>(xy + 2 * nd[r]);
         nu[r] = *reinterpret_cast<const double2*>(U + 2 * nd[r]);
     }
@@ -983,7 +979,7 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
     double pv[EPT][4], mv[EPT][4];
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
-        if (r * TPB + (int)(threadIdx.x & ~63u) >= L) continue;
+        if (r * TPB + (int)(threadIdx.x & ~63u) >= n_el) continue;
         const int i = r * TPB + (int)threadIdx.x;
         const int64_t e = el[r];
         enw[r] = el_nodes[(int64_t)wg * L + (i < L ? i : 0)];
@@ -1010,7 +1006,7 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
 #pragma unroll
     for (int r = 0; r < NPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
-        if (i < NL) { lxy[i] = nxy[r]; lu[i] = nu[r]; }
+        if (i < n_nd) { lxy[i] = nxy[r]; lu[i] = nu[r]; }
     }
 #pragma unroll
     for (int q = 0; q < CWPT; ++q) {
@@ -1025,7 +1021,7 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
         const int i = r * TPB + (int)threadIdx.x;
         int branch = 0;
         bool own = false;
-        if (i < L) {
+        if (i < n_el) {
             const uint32_t wv = enw[r];
             const int64_t e = el[r];
             own = (wv >> 30) & 1u;

@@ -47,6 +47,16 @@ int main(int argc, char** argv) {
         if (tstart[i] - tstart[i - 1] > 256 || tstart[i] < tstart[i - 1]) return 1;
     int rc = 0;
     if (n_p == 3) {
+        for (int segs = 1; segs <= kSegMax; ++segs) {       // the raw tilings, before build_p1_plan chooses
+            P1Plan P;
+            r = build_p1_plan_segs(S, n_e, n_n, elem.data(), P1Options(), segs, P);
+            const int bad = r == FEP_OK ? validate_p1_plan(P, S, n_e, n_n, elem.data()) : -1;
+            std::printf("tiling with <= %d segment(s): rc %d check %d tiles %lld staged %lld (%.3f per element) nodes %lld L %d C %d NL %d "
+                        "lds %d rng %d pk %d fused %d/%d\n", segs, r, bad, (long long)P.n_wg, (long long)P.staged_total,
+                        (double)P.staged_total / (double)n_e, (long long)P.staged_nodes_total, P.L, P.C, P.NL, (int)P.lds, (int)P.rng,
+                        (int)P.pk, (int)P.fused, (int)P.fused_rng);
+            if (r != FEP_OK || bad) rc = 1;
+        }
         struct Case { const char* name; bool lds, rng, pk, fused; int segs; };
         const Case cases[] = {{"default", true, true, true, true, max_segs}, {"one segment", true, true, true, true, 1},
                               {"lists", true, false, true, true, max_segs}, {"unpacked", true, true, false, true, max_segs},

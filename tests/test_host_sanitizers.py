@@ -82,7 +82,7 @@ def test_host_native_code_under_sanitizers(fep, binaries, tmp_path, kind):
             assert res.returncode == 0 and 'result ok' in res.stdout, (name, res.stdout[-3000:])
             assert 'runtime error' not in res.stdout and 'Sanitizer' not in res.stdout, (name, res.stdout[-3000:])
             if elem.shape[0] == 3:
-                assert res.stdout.count('check 0') == 7, res.stdout
+                assert res.stdout.count('check 0') == 11, res.stdout               # 4 raw tilings + 7 plan variants, all validated
 
 
 def test_two_row_tiles_stage_fewer_elements_on_a_row_numbered_mesh(fep, binaries, tmp_path):
