@@ -27,6 +27,8 @@ PROTOTYPES = {
     'fep_memcpy_h2d': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     'fep_memcpy_d2h': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     'fep_sync': (C.c_int, [C.c_int, C.c_void_p]),
+    'fep_host_alloc': (C.c_int, [c_void_pp, C.c_int64]),
+    'fep_host_free': (C.c_int, [C.c_void_p]),
     'fep_return_map_host': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -45,6 +47,8 @@ PROTOTYPES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_step_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_step_host_planar': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_gather_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -112,3 +116,39 @@ def check(code, where):
 def ptr(a):
     """void* of a NumPy array (or None)."""
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _PinnedBlock:
+    """Owner of one page-locked block of the library's cache (fep_host_alloc); the block goes back to the cache when
+    the last NumPy view of it is gone."""
+    __slots__ = ('ptr',)
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().fep_host_alloc(C.byref(p), nbytes), 'fep_host_alloc')
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().fep_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=None):
+    """np.empty in page-locked memory: the *_host entry points DMA results straight into it (no staging copy on the
+    way back).  The array's base chain ends in a ctypes buffer that owns the block, so slices and views keep it alive
+    like any NumPy base and the block returns to the cache with the last of them."""
+    import numpy as np
+    dt = np.dtype(np.float64 if dtype is None else dtype)
+    shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(int(v) for v in shape)
+    n = 1
+    for v in shape:
+        n *= v
+    nbytes = max(n * dt.itemsize, 1)
+    blk = _PinnedBlock(nbytes)
+    buf = (C.c_char * nbytes).from_address(blk.ptr)
+    buf._fep_owner = blk                               # ctypes objects take attributes: ties the block to the buffer
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)

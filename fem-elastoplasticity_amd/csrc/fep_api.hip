@@ -3,8 +3,10 @@
 #include "fep_common.h"
 #include "fep_host.h"
 #include "fep_kernels.hip.h"
+#include "fep_staging.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +65,9 @@ struct fep_ctx {
     double *s_int = nullptr, *ds_int = nullptr;     // used when the caller does not ask for s / ds
     uint2* blk_counts = nullptr;
     int n_count_blocks = 0;
+    // persistent device buffers of the *_host entry points (u, ep, e, s, ds, ind_p, k, f, counts, q)
+    void* hbuf[12] = {};
+    size_t hbuf_bytes[12] = {};
     // host copies of the pattern
     std::vector<int32_t> indptr, indices;
     // in-situ profiling: 4 events per step (before element, after element, after csr, after force)
@@ -91,23 +96,6 @@ template <class T> static int upload(T** p, const T* src, int64_t count) {
     if (count > 0) HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
     return FEP_OK;
 }
-
-// RAII for temporary device buffers of the *_host entry points
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(int64_t bytes) { HIP_TRY(hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 1))); return FEP_OK; }
-    int from(const void* h, int64_t bytes) {
-        FEP_TRY(alloc(bytes));
-        if (bytes > 0) HIP_TRY(hipMemcpy(p, h, (size_t)bytes, hipMemcpyHostToDevice));
-        return FEP_OK;
-    }
-    int to(void* h, int64_t bytes) const {
-        if (bytes > 0) HIP_TRY(hipMemcpy(h, p, (size_t)bytes, hipMemcpyDeviceToHost));
-        return FEP_OK;
-    }
-    template <class T> T* as() const { return (T*)p; }
-};
 
 static inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
@@ -209,11 +197,34 @@ extern "C" int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
     return FEP_OK;
 }
 
-extern "C" int fep_return_map_host(int device_id, int64_t n_int,
-                                   const double* e_h, int64_t e_pt_stride, int64_t e_comp_stride,
-                                   const double* e0_h, double* ep_prev_h,
-                                   const double* shear_h, const double* bulk_h, const double* eta_h, const double* c_h,
-                                   int accept, double* s_h, double* ds_h, uint8_t* ind_p_h, int64_t* counts_h) {
+// persistent device buffer `idx` of a context's host entry points (sizes are fixed by the mesh: allocated once)
+static int ctx_buf(fep_ctx* c, int idx, int64_t bytes, void** out) {
+    if (bytes <= 0) bytes = 1;
+    if (c->hbuf_bytes[idx] < (size_t)bytes) {
+        if (c->hbuf[idx]) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->hbuf[idx])); c->hbuf[idx] = nullptr; c->hbuf_bytes[idx] = 0; }
+        HIP_TRY(hipMalloc(&c->hbuf[idx], (size_t)bytes));
+        c->hbuf_bytes[idx] = (size_t)bytes;
+    }
+    *out = c->hbuf[idx];
+    return FEP_OK;
+}
+
+extern "C" int fep_host_alloc(void** ptr_h, int64_t bytes) {
+    if (!ptr_h || bytes < 0) return FEP_EINVAL;
+    *ptr_h = nullptr;
+    try { return fep_stage::pinned().alloc(ptr_h, (size_t)bytes); }
+    catch (...) { return FEP_ENOMEM; }
+}
+extern "C" int fep_host_free(void* ptr_h) {
+    try { return fep_stage::pinned().release(ptr_h); }
+    catch (...) { return FEP_ENOMEM; }
+}
+
+static int return_map_host_impl(int device_id, int64_t n_int,
+                                const double* e_h, int64_t e_pt_stride, int64_t e_comp_stride,
+                                const double* e0_h, double* ep_prev_h,
+                                const double* shear_h, const double* bulk_h, const double* eta_h, const double* c_h,
+                                int accept, double* s_h, double* ds_h, uint8_t* ind_p_h, int64_t* counts_h) {
     if (n_int < 0) return FEP_EINVAL;
     if (n_int > 0 && (!e_h || !shear_h || !bulk_h || !eta_h || !c_h)) return FEP_EINVAL;
     if (counts_h) { counts_h[0] = 0; counts_h[1] = 0; }
@@ -223,24 +234,53 @@ extern "C" int fep_return_map_host(int device_id, int64_t n_int,
     const int64_t span = (n_int - 1) * e_pt_stride + 2 * e_comp_stride + 1;
     if (e_pt_stride <= 0 || e_comp_stride <= 0 || span < 3 * n_int) return FEP_EINVAL;
     const int64_t nb = n_int * (int64_t)sizeof(double);
-    DevBuf e, ep, sh, bu, et, cc, s, ds, ip, cnt;
-    FEP_TRY(e.from(e_h, span * (int64_t)sizeof(double)));
-    if (ep_prev_h) FEP_TRY(ep.from(ep_prev_h, 4 * nb));
-    FEP_TRY(sh.from(shear_h, nb)); FEP_TRY(bu.from(bulk_h, nb)); FEP_TRY(et.from(eta_h, nb)); FEP_TRY(cc.from(c_h, nb));
-    if (s_h) FEP_TRY(s.alloc(4 * nb));
-    if (ds_h) FEP_TRY(ds.alloc(9 * nb));
-    if (ind_p_h) FEP_TRY(ip.alloc(n_int));
-    FEP_TRY(cnt.alloc(2 * sizeof(int64_t)));
-    FEP_TRY(fep_return_map_dev(device_id, nullptr, n_int, e.as<double>(), e_pt_stride, e_comp_stride, e0_h,
-                               ep.as<double>(), sh.as<double>(), bu.as<double>(), et.as<double>(), cc.as<double>(),
-                               accept, s.as<double>(), ds.as<double>(), ip.as<uint8_t>(), cnt.as<int64_t>()));
-    HIP_TRY(hipDeviceSynchronize());
-    if (s_h) FEP_TRY(s.to(s_h, 4 * nb));
-    if (ds_h) FEP_TRY(ds.to(ds_h, 9 * nb));
-    if (ind_p_h) FEP_TRY(ip.to(ind_p_h, n_int));
-    if (counts_h) FEP_TRY(cnt.to(counts_h, 2 * sizeof(int64_t)));
-    if (accept && ep_prev_h) FEP_TRY(ep.to(ep_prev_h, 4 * nb));
-    return FEP_OK;
+    fep_stage::Engine* E = nullptr;
+    FEP_TRY(fep_stage::engine(device_id, &E));
+    std::lock_guard<std::mutex> lock(E->call);
+    void *e = nullptr, *ep = nullptr, *sh, *bu, *et, *cc, *s = nullptr, *ds = nullptr, *ip = nullptr, *cnt;
+    FEP_TRY(E->buffer(0, span * (int64_t)sizeof(double), &e));
+    if (ep_prev_h) FEP_TRY(E->buffer(1, 4 * nb, &ep));
+    FEP_TRY(E->buffer(2, nb, &sh)); FEP_TRY(E->buffer(3, nb, &bu)); FEP_TRY(E->buffer(4, nb, &et)); FEP_TRY(E->buffer(5, nb, &cc));
+    if (s_h) FEP_TRY(E->buffer(6, 4 * nb, &s));
+    if (ds_h) FEP_TRY(E->buffer(7, 9 * nb, &ds));
+    if (ind_p_h) FEP_TRY(E->buffer(8, n_int, &ip));
+    FEP_TRY(E->buffer(9, 2 * sizeof(int64_t), &cnt));
+    static const bool timing = std::getenv("FEP_TIME_HOST") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    FEP_TRY(E->h2d(e, e_h, (size_t)span * sizeof(double)));
+    if (ep_prev_h) FEP_TRY(E->h2d(ep, ep_prev_h, (size_t)(4 * nb)));
+    FEP_TRY(E->h2d(sh, shear_h, (size_t)nb)); FEP_TRY(E->h2d(bu, bulk_h, (size_t)nb));
+    FEP_TRY(E->h2d(et, eta_h, (size_t)nb)); FEP_TRY(E->h2d(cc, c_h, (size_t)nb));
+    if (timing) {
+        (void)hipStreamSynchronize(E->stream);
+        std::fprintf(stderr, "[fep] return_map_host: inputs on the device after %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    FEP_TRY(fep_return_map_dev(device_id, E->stream, n_int, (const double*)e, e_pt_stride, e_comp_stride, e0_h, (double*)ep,
+                               (const double*)sh, (const double*)bu, (const double*)et, (const double*)cc, accept, (double*)s,
+                               (double*)ds, (uint8_t*)ip, (int64_t*)cnt));
+    if (s_h) FEP_TRY(E->d2h(s_h, s, (size_t)(4 * nb)));
+    if (ds_h) FEP_TRY(E->d2h(ds_h, ds, (size_t)(9 * nb)));
+    if (ind_p_h) FEP_TRY(E->d2h(ind_p_h, ip, (size_t)n_int));
+    if (counts_h) FEP_TRY(E->d2h(counts_h, cnt, 2 * sizeof(int64_t)));
+    if (accept && ep_prev_h) FEP_TRY(E->d2h(ep_prev_h, ep, (size_t)(4 * nb)));
+    const int rf = E->finish();
+    if (timing)
+        std::fprintf(stderr, "[fep] return_map_host: done after %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return rf;
+}
+
+#define FEP_GUARD(call) \
+    try { return call; } catch (const std::bad_alloc&) { return FEP_ENOMEM; } catch (...) { return FEP_EINVAL; }
+
+extern "C" int fep_return_map_host(int device_id, int64_t n_int,
+                                   const double* e_h, int64_t e_pt_stride, int64_t e_comp_stride,
+                                   const double* e0_h, double* ep_prev_h,
+                                   const double* shear_h, const double* bulk_h, const double* eta_h, const double* c_h,
+                                   int accept, double* s_h, double* ds_h, uint8_t* ind_p_h, int64_t* counts_h) {
+    FEP_GUARD(return_map_host_impl(device_id, n_int, e_h, e_pt_stride, e_comp_stride, e0_h, ep_prev_h, shear_h, bulk_h, eta_h,
+                                   c_h, accept, s_h, ds_h, ind_p_h, counts_h))
 }
 
 using fep_host::Symbolic;
@@ -277,6 +317,8 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+        for (void* p : c->hbuf)
+            if (p) (void)hipFree(p);
     }
     delete c;
     return FEP_OK;
@@ -841,51 +883,75 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
     return launch_reduce(c, st, k_data_d, f_out_d);
 }
 
-extern "C" int fep_step_host(fep_ctx* c, const double* u_h, const double* e0_h, double* ep_prev_h, int accept,
-                             double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
-                             double* k_data_h, double* f_out_h, int64_t* counts_h) {
+static int step_host_impl(fep_ctx* c, bool u_planar, const double* u_h, const double* e0_h, double* ep_prev_h, int accept,
+                          double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
+                          double* k_data_h, double* f_out_h, int64_t* counts_h) {
     if (!c || !u_h) return FEP_EINVAL;
     FEP_TRY(fep_set_device(c->device));
     const int64_t nb = c->n_int * (int64_t)sizeof(double);
-    DevBuf u, ep, eo, s, ds, ip, kd, f, cnt;
-    FEP_TRY(u.from(u_h, c->n_dof * (int64_t)sizeof(double)));
-    if (ep_prev_h) FEP_TRY(ep.from(ep_prev_h, 4 * nb));
-    if (e_out_h) FEP_TRY(eo.alloc(3 * nb));
-    if (s_h) FEP_TRY(s.alloc(4 * nb));
-    if (ds_h) FEP_TRY(ds.alloc(9 * nb));
-    if (ind_p_h) FEP_TRY(ip.alloc(c->n_int));
-    if (k_data_h) FEP_TRY(kd.alloc(c->nnz * (int64_t)sizeof(double)));
-    if (f_out_h) FEP_TRY(f.alloc(c->n_dof * (int64_t)sizeof(double)));
-    FEP_TRY(cnt.alloc(2 * sizeof(int64_t)));
-    FEP_TRY(fep_step_dev(c, nullptr, u.as<double>(), e0_h, ep.as<double>(), accept, eo.as<double>(), s.as<double>(),
-                         ds.as<double>(), ip.as<uint8_t>(), kd.as<double>(), f.as<double>(), cnt.as<int64_t>()));
-    HIP_TRY(hipDeviceSynchronize());
-    if (e_out_h) FEP_TRY(eo.to(e_out_h, 3 * nb));
-    if (s_h) FEP_TRY(s.to(s_h, 4 * nb));
-    if (ds_h) FEP_TRY(ds.to(ds_h, 9 * nb));
-    if (ind_p_h) FEP_TRY(ip.to(ind_p_h, c->n_int));
-    if (k_data_h) FEP_TRY(kd.to(k_data_h, c->nnz * (int64_t)sizeof(double)));
-    if (f_out_h) FEP_TRY(f.to(f_out_h, c->n_dof * (int64_t)sizeof(double)));
-    if (counts_h) FEP_TRY(cnt.to(counts_h, 2 * sizeof(int64_t)));
-    if (accept && ep_prev_h) FEP_TRY(ep.to(ep_prev_h, 4 * nb));
-    return FEP_OK;
+    fep_stage::Engine* E = nullptr;
+    FEP_TRY(fep_stage::engine(c->device, &E));
+    std::lock_guard<std::mutex> lock(E->call);
+    void *u, *ep = nullptr, *eo = nullptr, *s = nullptr, *ds = nullptr, *ip = nullptr, *kd = nullptr, *f = nullptr, *cnt;
+    FEP_TRY(ctx_buf(c, 0, c->n_dof * (int64_t)sizeof(double), &u));
+    if (ep_prev_h) FEP_TRY(ctx_buf(c, 1, 4 * nb, &ep));
+    if (e_out_h) FEP_TRY(ctx_buf(c, 2, 3 * nb, &eo));
+    if (s_h) FEP_TRY(ctx_buf(c, 3, 4 * nb, &s));
+    if (ds_h) FEP_TRY(ctx_buf(c, 4, 9 * nb, &ds));
+    if (ind_p_h) FEP_TRY(ctx_buf(c, 5, c->n_int, &ip));
+    if (k_data_h) FEP_TRY(ctx_buf(c, 6, c->nnz * (int64_t)sizeof(double), &kd));
+    if (f_out_h) FEP_TRY(ctx_buf(c, 7, c->n_dof * (int64_t)sizeof(double), &f));
+    FEP_TRY(ctx_buf(c, 8, 2 * sizeof(int64_t), &cnt));
+    if (u_planar) FEP_TRY(E->h2d_interleave2(u, u_h, (size_t)c->n_n));
+    else FEP_TRY(E->h2d(u, u_h, (size_t)c->n_dof * sizeof(double)));
+    if (ep_prev_h) FEP_TRY(E->h2d(ep, ep_prev_h, (size_t)(4 * nb)));
+    FEP_TRY(fep_step_dev(c, E->stream, (const double*)u, e0_h, (double*)ep, accept, (double*)eo, (double*)s, (double*)ds,
+                         (uint8_t*)ip, (double*)kd, (double*)f, (int64_t*)cnt));
+    // the largest result first: its transfer hides the others' set-up
+    if (k_data_h) FEP_TRY(E->d2h(k_data_h, kd, (size_t)c->nnz * sizeof(double)));
+    if (f_out_h) FEP_TRY(E->d2h(f_out_h, f, (size_t)c->n_dof * sizeof(double)));
+    if (ds_h) FEP_TRY(E->d2h(ds_h, ds, (size_t)(9 * nb)));
+    if (s_h) FEP_TRY(E->d2h(s_h, s, (size_t)(4 * nb)));
+    if (e_out_h) FEP_TRY(E->d2h(e_out_h, eo, (size_t)(3 * nb)));
+    if (ind_p_h) FEP_TRY(E->d2h(ind_p_h, ip, (size_t)c->n_int));
+    if (counts_h) FEP_TRY(E->d2h(counts_h, cnt, 2 * sizeof(int64_t)));
+    if (accept && ep_prev_h) FEP_TRY(E->d2h(ep_prev_h, ep, (size_t)(4 * nb)));
+    return E->finish();
 }
 
-extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s_h, double* k_data_h, double* f_out_h) {
+extern "C" int fep_step_host(fep_ctx* c, const double* u_h, const double* e0_h, double* ep_prev_h, int accept,
+                             double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
+                             double* k_data_h, double* f_out_h, int64_t* counts_h) {
+    FEP_GUARD(step_host_impl(c, false, u_h, e0_h, ep_prev_h, accept, e_out_h, s_h, ds_h, ind_p_h, k_data_h, f_out_h, counts_h))
+}
+
+extern "C" int fep_step_host_planar(fep_ctx* c, const double* u2_h, const double* e0_h, double* ep_prev_h, int accept,
+                                    double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
+                                    double* k_data_h, double* f_out_h, int64_t* counts_h) {
+    FEP_GUARD(step_host_impl(c, true, u2_h, e0_h, ep_prev_h, accept, e_out_h, s_h, ds_h, ind_p_h, k_data_h, f_out_h, counts_h))
+}
+
+static int assemble_host_impl(fep_ctx* c, const double* ds_h, const double* s_h, double* k_data_h, double* f_out_h) {
     if (!c) return FEP_EINVAL;
     if ((k_data_h && !ds_h) || (f_out_h && !s_h)) return FEP_EINVAL;
     FEP_TRY(fep_set_device(c->device));
     const int64_t nb = c->n_int * (int64_t)sizeof(double);
-    DevBuf ds, s, kd, f;
-    if (ds_h) FEP_TRY(ds.from(ds_h, 9 * nb));
-    if (s_h) FEP_TRY(s.from(s_h, 3 * nb));
-    if (k_data_h) FEP_TRY(kd.alloc(c->nnz * (int64_t)sizeof(double)));
-    if (f_out_h) FEP_TRY(f.alloc(c->n_dof * (int64_t)sizeof(double)));
-    FEP_TRY(fep_assemble_dev(c, nullptr, ds.as<double>(), s.as<double>(), kd.as<double>(), f.as<double>()));
-    HIP_TRY(hipDeviceSynchronize());
-    if (k_data_h) FEP_TRY(kd.to(k_data_h, c->nnz * (int64_t)sizeof(double)));
-    if (f_out_h) FEP_TRY(f.to(f_out_h, c->n_dof * (int64_t)sizeof(double)));
-    return FEP_OK;
+    fep_stage::Engine* E = nullptr;
+    FEP_TRY(fep_stage::engine(c->device, &E));
+    std::lock_guard<std::mutex> lock(E->call);
+    void *ds = nullptr, *s = nullptr, *kd = nullptr, *f = nullptr;
+    if (ds_h) { FEP_TRY(ctx_buf(c, 4, 9 * nb, &ds)); FEP_TRY(E->h2d(ds, ds_h, (size_t)(9 * nb))); }
+    if (s_h) { FEP_TRY(ctx_buf(c, 3, 4 * nb, &s)); FEP_TRY(E->h2d(s, s_h, (size_t)(3 * nb))); }
+    if (k_data_h) FEP_TRY(ctx_buf(c, 6, c->nnz * (int64_t)sizeof(double), &kd));
+    if (f_out_h) FEP_TRY(ctx_buf(c, 7, c->n_dof * (int64_t)sizeof(double), &f));
+    FEP_TRY(fep_assemble_dev(c, E->stream, (const double*)ds, (const double*)s, (double*)kd, (double*)f));
+    if (k_data_h) FEP_TRY(E->d2h(k_data_h, kd, (size_t)c->nnz * sizeof(double)));
+    if (f_out_h) FEP_TRY(E->d2h(f_out_h, f, (size_t)c->n_dof * sizeof(double)));
+    return E->finish();
+}
+
+extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s_h, double* k_data_h, double* f_out_h) {
+    FEP_GUARD(assemble_host_impl(c, ds_h, s_h, k_data_h, f_out_h))
 }
 
 extern "C" int fep_gather_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* idx_d, double* dst_d) {
@@ -917,15 +983,23 @@ extern "C" int fep_transform_dev(fep_ctx* c, void* stream, const double* q_int_d
     return FEP_OK;
 }
 
-extern "C" int fep_transform_host(fep_ctx* c, const double* q_int_h, double* q_node_h) {
+static int transform_host_impl(fep_ctx* c, const double* q_int_h, double* q_node_h) {
     if (!c || !q_int_h || !q_node_h) return FEP_EINVAL;
     FEP_TRY(fep_set_device(c->device));
-    DevBuf q, o;
-    FEP_TRY(q.from(q_int_h, c->n_int * (int64_t)sizeof(double)));
-    FEP_TRY(o.alloc(c->n_n * (int64_t)sizeof(double)));
-    FEP_TRY(fep_transform_dev(c, nullptr, q.as<double>(), o.as<double>()));
-    HIP_TRY(hipDeviceSynchronize());
-    return o.to(q_node_h, c->n_n * (int64_t)sizeof(double));
+    fep_stage::Engine* E = nullptr;
+    FEP_TRY(fep_stage::engine(c->device, &E));
+    std::lock_guard<std::mutex> lock(E->call);
+    void *q, *o;
+    FEP_TRY(ctx_buf(c, 9, c->n_int * (int64_t)sizeof(double), &q));
+    FEP_TRY(ctx_buf(c, 10, c->n_n * (int64_t)sizeof(double), &o));
+    FEP_TRY(E->h2d(q, q_int_h, (size_t)c->n_int * sizeof(double)));
+    FEP_TRY(fep_transform_dev(c, E->stream, (const double*)q, (double*)o));
+    FEP_TRY(E->d2h(q_node_h, o, (size_t)c->n_n * sizeof(double)));
+    return E->finish();
+}
+
+extern "C" int fep_transform_host(fep_ctx* c, const double* q_int_h, double* q_node_h) {
+    FEP_GUARD(transform_host_impl(c, q_int_h, q_node_h))
 }
 
 extern "C" int fep_ctx_profile_begin(fep_ctx* c) {

@@ -66,12 +66,13 @@ def _return_map(e, e0, ep_prev, shear, bulk, eta, c, apply_plastic_strain, tsx, 
     if ep_prev is not None:
         if ep_prev.shape != (4, n_int):
             raise ValueError(f'ep_prev must be (4,{n_int})')
-        inplace = (apply_plastic_strain and isinstance(ep_prev, np.ndarray) and ep_prev.dtype == np.float64
-                   and ep_prev.flags.c_contiguous and ep_prev.flags.writeable)
-        ep_dev = ep_prev if inplace else _f64(ep_prev).copy()
-    s = np.empty((4, n_int))
-    ds = np.empty((9, n_int))
-    ind = np.empty(n_int, dtype=np.uint8)
+        # the kernel writes the plastic strain only on accepting calls: otherwise the caller's array is read in place
+        direct = (isinstance(ep_prev, np.ndarray) and ep_prev.dtype == np.float64 and ep_prev.flags.c_contiguous
+                  and (ep_prev.flags.writeable or not apply_plastic_strain))
+        ep_dev = ep_prev if direct else _f64(ep_prev).copy()
+    s = _lib.pinned_empty((4, n_int))                  # outputs in page-locked memory: DMA-ed straight into them
+    ds = _lib.pinned_empty((9, n_int))
+    ind = _lib.pinned_empty(n_int, np.uint8)
     counts = np.zeros(2, dtype=np.int64)
     accept = bool(apply_plastic_strain) and ep_prev is not None
     _lib.check(l.fep_return_map_host(dev, n_int, _lib.ptr(ev), ps, cs, _lib.ptr(e0v), _lib.ptr(ep_dev),
@@ -79,7 +80,7 @@ def _return_map(e, e0, ep_prev, shear, bulk, eta, c, apply_plastic_strain, tsx, 
                                      _lib.ptr(s), _lib.ptr(ds), _lib.ptr(ind), _lib.ptr(counts)),
                'fep_return_map_host')
     n_smooth, n_apex = int(counts[0]), int(counts[1])
-    out = {'s': s, 'ds': ds, 'ind_p': ind.view(np.bool_), 'n_smooth': n_smooth, 'n_apex': n_apex}
+    out = _Result({'s': s, 'ds': ds, 'ind_p': ind.view(np.bool_), 'n_smooth': n_smooth, 'n_apex': n_apex})
     early_out = tsx and n_smooth == 0 and n_apex == 0                  # TSX:1103
     # C2: lambda_final is None in DP always, in TSX whenever a point is plastic
     out['lambda_final'] = np.zeros((1, n_int)) if early_out else None
@@ -90,8 +91,73 @@ def _return_map(e, e0, ep_prev, shear, bulk, eta, c, apply_plastic_strain, tsx, 
             ep_prev[...] = ep_dev                                      # C4: caller's array is mutated
         out['ep'] = ep_prev                                            # and returned as 'ep' (DP:751)
     else:
-        out['ep'] = np.zeros((4, n_int))                               # DP:749
+        out.lazy_zeros('ep', (4, n_int))                               # DP:749: zeros nobody reads on a Newton iterate
     return out
+
+
+class _Result(dict):
+    """The reference's result dict.  A non-accepting call returns 'ep' = zeros((4, n_int)) (DP:749) that the Newton
+    iterates never look at; the 32 MB array is created when the key is first touched (any read access to the dict
+    that could see it materialises it first), so that the per-iterate call does not pay for it."""
+    __slots__ = ('_lazy',)
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def lazy_zeros(self, key, shape):
+        self._lazy[key] = shape
+
+    def _fill(self):
+        if self._lazy:
+            for k, shape in self._lazy.items():
+                super().__setitem__(k, np.zeros(shape))
+            self._lazy = {}
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            self._fill()
+            return super().__getitem__(key)
+        raise KeyError(key)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+    def __contains__(self, key):
+        return key in self._lazy or super().__contains__(key)
+
+    def get(self, key, default=None):
+        self._fill()
+        return super().get(key, default)
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+    def copy(self):
+        self._fill()
+        return dict(self)
 
 
 def construct_constitutive_problem(e, ep_prev, shear, bulk, eta, c, apply_plastic_strain=False, device=None):
@@ -208,9 +274,12 @@ class MeshContext:
         'E' (3,n_int), 's' (4,n_int), 'ds' (9,n_int), 'ind_p', 'K' (csr), 'F' (n_dof,), plus
         'n_smooth', 'n_apex'.  `ep_prev` (4,n_int) is updated in place on accept."""
         U = np.asarray(U, dtype=np.float64)
-        u = np.ascontiguousarray(U.reshape(-1, order='F') if U.ndim == 2 else U)
-        if u.size != self.n_dof:
+        if U.size != self.n_dof:
             raise ValueError(f'U must hold {self.n_dof} values')
+        # the reference's (2, n_n) array goes down as it is: the library interleaves it while staging the transfer
+        # (a NumPy `reshape(-1, order='F')` of 1 M nodes costs 2.5 ms, as much as the whole transfer)
+        planar = U.ndim == 2 and U.shape[0] == 2 and U.flags.c_contiguous
+        u = U if planar else np.ascontiguousarray(U.reshape(-1, order='F') if U.ndim == 2 else U)
         n = self.n_int
         e0v = None if e0 is None else _f64(e0).ravel()
         ep = None
@@ -218,17 +287,17 @@ class MeshContext:
             ok = (ep_prev.dtype == np.float64 and ep_prev.flags.c_contiguous and ep_prev.shape == (4, n))
             ep = ep_prev if ok else _f64(ep_prev, (4, n)).copy()
         out = {}
-        E = np.empty((3, n)) if 'E' in want else None
-        s = np.empty((4, n)) if 's' in want else None
-        ds = np.empty((9, n)) if 'ds' in want else None
-        ind = np.empty(n, dtype=np.uint8) if 'ind_p' in want else None
-        kd = np.empty(self.nnz) if 'K' in want else None
-        F = np.empty(self.n_dof) if 'F' in want else None
+        E = _lib.pinned_empty((3, n)) if 'E' in want else None          # page-locked: results are DMA-ed straight into them
+        s = _lib.pinned_empty((4, n)) if 's' in want else None
+        ds = _lib.pinned_empty((9, n)) if 'ds' in want else None
+        ind = _lib.pinned_empty(n, np.uint8) if 'ind_p' in want else None
+        kd = _lib.pinned_empty(self.nnz) if 'K' in want else None
+        F = _lib.pinned_empty(self.n_dof) if 'F' in want else None
         counts = np.zeros(2, dtype=np.int64)
         accept = bool(apply_plastic_strain) and ep is not None
-        _lib.check(_lib.lib().fep_step_host(self._h, _lib.ptr(u), _lib.ptr(e0v), _lib.ptr(ep), int(accept),
-                                            _lib.ptr(E), _lib.ptr(s), _lib.ptr(ds), _lib.ptr(ind), _lib.ptr(kd),
-                                            _lib.ptr(F), _lib.ptr(counts)), 'fep_step_host')
+        fn = _lib.lib().fep_step_host_planar if planar else _lib.lib().fep_step_host
+        _lib.check(fn(self._h, _lib.ptr(u), _lib.ptr(e0v), _lib.ptr(ep), int(accept), _lib.ptr(E), _lib.ptr(s), _lib.ptr(ds),
+                      _lib.ptr(ind), _lib.ptr(kd), _lib.ptr(F), _lib.ptr(counts)), 'fep_step_host')
         if accept and ep is not ep_prev:
             ep_prev[...] = ep
         for k, v in (('E', E), ('s', s), ('ds', ds), ('F', F)):
@@ -247,8 +316,8 @@ class MeshContext:
         n = self.n_int
         dsv = None if ds is None else _f64(ds, (9, n))
         sv = None if s is None else _f64(np.asarray(s)[0:3], (3, n))
-        kd = np.empty(self.nnz) if ds is not None else None
-        F = np.empty(self.n_dof) if s is not None else None
+        kd = _lib.pinned_empty(self.nnz) if ds is not None else None
+        F = _lib.pinned_empty(self.n_dof) if s is not None else None
         _lib.check(_lib.lib().fep_assemble_host(self._h, _lib.ptr(dsv), _lib.ptr(sv), _lib.ptr(kd), _lib.ptr(F)),
                    'fep_assemble_host')
         return (None if kd is None else self.csr(kd)), F

@@ -24,7 +24,8 @@
  *     aligned (hipMalloc and every tensor library deliver that; checked, FEP_EINVAL otherwise): the kernels move
  *     them as (x, y) pairs;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); *_dev
- *     calls only enqueue work and return, *_host calls are synchronous;
+ *     calls only enqueue work and return, *_host calls are synchronous (they run on a stream of the library's own,
+ *     with persistent device buffers and pinned staging: no allocation per call after the first);
  *   - calls on one context are not re-entrant; one context per (host thread, GPU).
  */
 #ifndef FEP_H
@@ -67,6 +68,12 @@ int fep_free(int device_id, void* ptr_d);
 int fep_memcpy_h2d(int device_id, void* dst_d, const void* src_h, int64_t bytes);
 int fep_memcpy_d2h(int device_id, void* dst_h, const void* src_d, int64_t bytes);
 int fep_sync(int device_id, void* stream);
+/* Page-locked host memory from a size-keyed cache (a returned block is reused by the next request of the same size;
+ * up to 4 GiB stay cached).  The *_host entry points DMA straight from / into such blocks; any other host pointer is
+ * staged through a ring of pinned slots filled by copy threads (FEP_COPY_THREADS, default 8).  The Python layer
+ * places every output array it hands to the caller (s, ds, ind_p, K data, F: DP:1044-1058) in such blocks. */
+int fep_host_alloc(void** ptr_h, int64_t bytes);
+int fep_host_free(void* ptr_h);
 
 /* ---- a2: return map, mesh-free (pointwise) --------------------------------------------
  * Replaces construct_constitutive_problem, DP:604-757 (e0_h == NULL) and TSX:990-1157
@@ -160,6 +167,13 @@ int fep_step_host(fep_ctx* ctx, const double* u_h, const double* e0_h,
                   double* ep_prev_h, int accept,
                   double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
                   double* k_data_h, double* f_out_h, int64_t* counts_h);
+
+/* The same with the displacement as the reference holds it: `u2_h` = the (2, n_n) C-ordered array `U` (DP:1043
+ * flattens it column-major on every iterate); the reordering into DOF order happens inside the staging copy. */
+int fep_step_host_planar(fep_ctx* ctx, const double* u2_h, const double* e0_h,
+                         double* ep_prev_h, int accept,
+                         double* e_out_h, double* s_h, double* ds_h, uint8_t* ind_p_h,
+                         double* k_data_h, double* f_out_h, int64_t* counts_h);
 
 /* ---- a3..a5 only: assembly from given ds / s ------------------------------------------
  * Replaces DP:1047-1050 + DP:1058 when the caller already holds `ds` (9,n_int) and `s` (>=3 rows
