@@ -24,6 +24,7 @@ from .sharding import Partition, ShardedContext, element_ranges
 from .newton import solve_strip_footing, solve_tsx_tunnel, transform
 from .solver import KrylovSolver, build_amg_hierarchy
 from .midpoints import create_midpoints, create_midpoints_P2, create_midpoints_P4
+from .meshio import dump_free_dof_csv, load_tsx_mesh
 from . import plasticity2d_dp, tsx_tunnel, elasticity2d
 
 __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get_local_basis_volume',
@@ -31,5 +32,5 @@ __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get
            'construct_constitutive_problem_tsx', 'get_elastic_stiffness_matrix', 'get_elastic_stiffness_matrix_el',
            'assemble_tangent', 'default_device', 'FepError', 'lib', 'lib_path', 'build',
            'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'KrylovSolver', 'build_amg_hierarchy', 'create_midpoints', 'create_midpoints_P2',
-           'create_midpoints_P4',
+           'create_midpoints_P4', 'load_tsx_mesh', 'dump_free_dof_csv',
            'plasticity2d_dp', 'tsx_tunnel', 'elasticity2d']

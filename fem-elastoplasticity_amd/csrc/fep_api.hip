@@ -25,6 +25,7 @@ struct fep_ctx {
     int n_p = 0, n_q = 0;
     int64_t n_e = 0, n_n = 0, n_int = 0, n_dof = 0, nnz = 0, n_blk = 0, n_contrib = 0;
     bool have_materials = false;
+    bool kc_aos = false;                                // K_e half-blocks: all blocks of an element adjacent (AoS) or block-major (SoA)
     bool elem_geo = true;                               // element_kernel: geometry from coordinates instead of the dphi arrays
     MatU matu{};                                        // homogeneous-material fast path (arrays not read)
     // device, static
@@ -485,6 +486,11 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
     CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
     if (!c->p1_node && !c->gn) {
+        // measured at ~1 M points per type (tools/elem_bench.py): the element-major layout pays for the 15-node element only
+        // (P4: step 1.47 -> 1.35 ms; P2 0.96 -> 1.06, Q2 0.82 -> 0.94, Q1 0.22 -> 0.26: their stores lose coalescing)
+        c->kc_aos = elem_type == FEP_P4;
+        if (const char* kl = std::getenv("FEP_KC_LAYOUT")) c->kc_aos = std::strcmp(kl, "aos") == 0;
+        if ((int64_t)sym_block_count(n_p) * n_e >= (int64_t)1 << 30) r = FEP_ERANGE;     // 2 * position fits int32
         {   // element_kernel stores half of the symmetric K_e: re-address the contributions (block, transposed)
             std::vector<int32_t> perm_sym(S.perm.size());
             for (size_t i = 0; i < S.perm.size(); ++i) {
@@ -492,8 +498,9 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 const int ab = (int)(v / n_e);
                 const int64_t e = v - (int64_t)ab * n_e;
                 int idx; bool tr;
-                sym_block_index(n_p, ab / n_p, ab % n_p, idx, tr);
-                perm_sym[i] = (int32_t)(2 * ((int64_t)idx * n_e + e) + (tr ? 1 : 0));
+                sym_block_index(n_p, ab / n_p, ab % n_p, idx, tr, c->kc_aos);
+                const int64_t pos = c->kc_aos ? e * sym_block_count(n_p) + idx : (int64_t)idx * n_e + e;
+                perm_sym[i] = (int32_t)(2 * pos + (tr ? 1 : 0));
             }
             CK(upload(&c->perm, perm_sym.data(), (int64_t)perm_sym.size()));
         }
@@ -609,7 +616,7 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
     hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO>), dim3(grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)),          \
                        dim3(kBlock), 0, st, c->n_e,                                                                     \
                        c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,       \
-                       c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts, Kc, fe)
+                       c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts, Kc, fe, c->kc_aos ? 1 : 0)
     if (c->elem_geo) ELEM_LAUNCH(true); else ELEM_LAUNCH(false);
 #undef ELEM_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -274,11 +274,14 @@ __device__ __forceinline__ void geometry_at_q(const double* __restrict__ t1, con
 struct MatU { double shear, bulk, eta, c; int on; };
 
 // Where element_kernel keeps the block (a, b) of K_e: index of the stored block and whether it is the transpose.
-inline __host__ __device__ void sym_block_index(int n_p, int a, int b, int& idx, bool& transposed) {
+// `row_major`: the stored blocks of an element are numbered a*(n_p/2+1) + j (a lane's blocks adjacent: the AoS layout,
+// Kc[(e*NB + idx)*4]) instead of j*n_p + a (the SoA layout, Kc[(idx*n_e + e)*4]).
+inline __host__ __device__ void sym_block_index(int n_p, int a, int b, int& idx, bool& transposed, bool row_major = false) {
     const int j = b >= a ? b - a : b - a + n_p;
     const bool direct = 2 * j < n_p || (2 * j == n_p && a < n_p / 2);
-    if (direct) { idx = j * n_p + a; transposed = false; }
-    else { idx = (n_p - j) * n_p + b; transposed = true; }
+    const int nj = n_p / 2 + 1;
+    if (direct) { idx = row_major ? a * nj + j : j * n_p + a; transposed = false; }
+    else { idx = row_major ? b * nj + (n_p - j) : (n_p - j) * n_p + b; transposed = true; }
 }
 inline __host__ __device__ int sym_block_count(int n_p) { return (n_p / 2 + 1) * n_p; }   // upper bound on idx + 1
 
@@ -306,8 +309,8 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                // outputs of phase 1 (FROM_U) or inputs (!FROM_U)
                double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
                uint2* blk_counts,
-               // outputs of phase 2
-               double* __restrict__ Kc, double* __restrict__ fe) {
+               // outputs of phase 2 (kc_aos: all stored blocks of an element adjacent, see sym_block_index)
+               double* __restrict__ Kc, double* __restrict__ fe, int kc_aos) {
     using C = ElemCfg<NP, NQ, GEO>;
     constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
     constexpr int NJ = NP / 2 + 1;                   // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
@@ -422,7 +425,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (NP % 2 == 0 && j == NP / 2 && a >= NP / 2) continue;     // held by the lane of node a - NP/2
-                double2* dst = reinterpret_cast<double2*>(Kc + ((int64_t)(j * NP + a) * n_e + e) * 4);
+                double2* dst = reinterpret_cast<double2*>(Kc + (kc_aos ? (e * (NJ * NP) + a * NJ + j) : ((int64_t)(j * NP + a) * n_e + e)) * 4);
                 dst[0] = make_double2(kk[j][0], kk[j][1]);
                 dst[1] = make_double2(kk[j][2], kk[j][3]);
             }

@@ -271,12 +271,18 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     return hist
 
 
-def solve_tsx_tunnel(coords, elem, element_type='P1', n_load_steps=17, monitor=(0, 40), device=None, log=None,
-                     linear_solver='direct', pcg_rtol=1e-11, pcg_forcing=None):
-    """TSX tunnel excavation (TSX:1637-1832) on a given mesh (`coords` (2,n_n), `elem` (n_p,n_e) 0-based; the
-    reference reads coord.csv / elem.csv and, for P2/P4, adds midpoints first).  Returns the history of the
-    monitored displacement, plastic-point counts and accepted displacements."""
+def solve_tsx_tunnel(coords=None, elem=None, element_type='P1', n_load_steps=17, monitor=(0, 40), device=None, log=None,
+                     linear_solver='direct', pcg_rtol=1e-11, pcg_forcing=None, mesh_dir=None):
+    """TSX tunnel excavation (TSX:1637-1832) on a given mesh (`coords` (2,n_n), `elem` (n_p,n_e) 0-based), or — as the
+    reference does at TSX:1687-1690 — on the mesh read from `mesh_dir`/coord.csv, elem.csv with the midpoints of
+    `element_type` added.  Returns the history of the monitored displacement, plastic-point counts and accepted
+    displacements."""
     t = _coerce(element_type)
+    if mesh_dir is not None:
+        from .meshio import load_tsx_mesh
+        coords, elem = load_tsx_mesh(mesh_dir, t)
+    if coords is None or elem is None:
+        raise ValueError('pass the mesh (coords, elem) or mesh_dir')
     young, nu = 60000, 0.2                                                                # TSX:1663-1672
     shear0 = young / (2 * (1 + nu))
     bulk0 = young / (3 * (1 - 2 * nu))

@@ -1,5 +1,6 @@
 """Host logic of the package (tables, mesh numbering) against arrays recorded from the reference."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -172,3 +173,42 @@ def test_host_transform_vs_reference_golden(fep, t):
     q, want = g[f'{t}_q_int'], g[f'{t}_q_node']
     got = fep.transform(q, g[f'{t}_elements'], g[f'{t}_weight'])
     assert np.abs(got - want).max() <= 1e-14 * np.abs(q).max()
+
+
+@pytest.mark.parametrize('t', ['P1', 'P2', 'P4'])
+def test_load_tsx_mesh_from_csv(fep, t):
+    """coord.csv / elem.csv (the reference's data files, copied as fixtures) -> exactly what TSX:1687-1690 builds:
+    0-based elements, P2 / P4 midpoints with the reference's numbering (arrays recorded from the reference)."""
+    import os
+    from conftest import GOLDEN
+    g = load_golden('tsx')
+    coord, elem = fep.load_tsx_mesh(os.path.join(GOLDEN, 'tsx_csv'), t)
+    kc, ke = {'P1': ('coord', 'elem'), 'P2': ('p2_coord', 'p2_elem'), 'P4': ('p4_coord', 'p4_elem')}[t]
+    assert coord.dtype == np.float64 and elem.dtype == np.int64 and elem.min() == 0
+    assert np.array_equal(coord, g[kc]) and np.array_equal(elem, g[ke])
+
+
+def test_load_tsx_mesh_rejects_bad_files(fep, tmp_path):
+    np.savetxt(tmp_path / 'coord.csv', np.zeros((2, 3)), delimiter=',')
+    np.savetxt(tmp_path / 'elem.csv', np.array([[1], [2], [4]]), delimiter=',', fmt='%d')      # node 4 of 3
+    with pytest.raises(IndexError):
+        fep.load_tsx_mesh(str(tmp_path))
+    np.savetxt(tmp_path / 'elem.csv', np.array([[1, 2], [2, 3]]), delimiter=',', fmt='%d')     # 2 rows
+    with pytest.raises(ValueError):
+        fep.load_tsx_mesh(str(tmp_path))
+    with pytest.raises(ValueError):
+        fep.load_tsx_mesh(os.path.join(os.path.dirname(__file__), 'golden', 'tsx_csv'), 'Q1')
+
+
+def test_dump_free_dof_csv_roundtrip(fep, tmp_path):
+    import scipy.sparse as ssp
+    rng = np.random.default_rng(0)
+    n_n = 7
+    Q = rng.random((2, n_n)) > 0.3
+    K = ssp.random(2 * n_n, 2 * n_n, density=0.4, random_state=1, format='csr')
+    F0, F = rng.normal(size=(2, n_n)), rng.normal(size=2 * n_n)
+    fep.dump_free_dof_csv(str(tmp_path), Q, K=K, F0=F0, F=F)
+    qf = Q.flatten(order='F')
+    assert np.allclose(np.genfromtxt(tmp_path / 'k_tangent_qq.csv', delimiter=','), K.toarray()[np.ix_(qf, qf)], rtol=1e-15)
+    assert np.allclose(np.genfromtxt(tmp_path / 'f0q.csv', delimiter=','), F0.flatten(order='F')[qf], rtol=1e-15)
+    assert np.allclose(np.genfromtxt(tmp_path / 'fq.csv', delimiter=','), F[qf], rtol=1e-15)

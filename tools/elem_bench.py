@@ -18,6 +18,7 @@ t = sys.argv[1]
 N = int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 mix = sys.argv[4] if len(sys.argv) > 4 else 'bands'
+kf_only = len(sys.argv) > 5 and sys.argv[5] == 'kf'      # what a Newton iterate asks for: K and F, no s / ds / ind_p
 t0 = time.time()
 if t == 'P4':                       # P4 meshes come from the midpoint generator (TSX:1354-1505) on a P1 mesh
     m1 = fep.square_mesh(N, 'P1', 10)
@@ -42,8 +43,11 @@ st = torch.cuda.current_stream().cuda_stream
 
 
 def step():
-    ctx.step_dev(st, U.data_ptr(), ep=Ep.data_ptr(), s=S.data_ptr(), ds=DS.data_ptr(), ind_p=ind.data_ptr(),
-                 k_data=Kd.data_ptr(), f_out=F.data_ptr(), counts=cnt.data_ptr())
+    if kf_only:
+        ctx.step_dev(st, U.data_ptr(), ep=Ep.data_ptr(), k_data=Kd.data_ptr(), f_out=F.data_ptr(), counts=cnt.data_ptr())
+    else:
+        ctx.step_dev(st, U.data_ptr(), ep=Ep.data_ptr(), s=S.data_ptr(), ds=DS.data_ptr(), ind_p=ind.data_ptr(),
+                     k_data=Kd.data_ptr(), f_out=F.data_ptr(), counts=cnt.data_ptr())
 
 
 for _ in range(3):
@@ -61,7 +65,7 @@ kms, _ = ctx.profile_end(st)
 n_p, n_q = fep.ELEMENT_SHAPE[fep.LagrangeElementType[t]]
 alg = (201 + 16 * n_p + 8 * (2 * n_p) ** 2 / n_q) * n
 c = cnt.cpu().tolist()
-print(f'{t} N={N} n_e={ctx.n_e} n_int={n} nnz={ctx.nnz} setup {t_setup:.1f}s  smooth/apex {c[0]}/{c[1]}  '
+print(f'{t}{" K/F-only" if kf_only else ""} N={N} n_e={ctx.n_e} n_int={n} nnz={ctx.nnz} setup {t_setup:.1f}s  smooth/apex {c[0]}/{c[1]}  '
       f'step {dt*1e3:.3f} ms -> {n/dt/1e9:.2f} G upd/s | kernels ms {({k: round(v, 4) for k, v in kms.items()})} | '
       f'alg {alg/1e6:.0f} MB -> element kernel {alg/(kms["element"]*1e-3)/1e12:.2f} TB/s, '
       f'whole step {alg/dt/1e12:.2f} TB/s')
