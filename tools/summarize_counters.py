@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Condenses the passes of tools/prof.sh into profiles/<tag>_kernel_stats.csv and profiles/<tag>_counters.csv
+(per kernel: average duration, FETCH_SIZE / WRITE_SIZE and the corrected HBM bytes 2*FETCH + WRITE per launch, the
+SQ counters per launch).  Reads rocprofv3's rocpd databases (ROCm 7.2 default output) or its CSV files.
+    python tools/summarize_counters.py TAG gpurun_out/prof_TAG"""
+import collections
+import csv
+import glob
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.replace('void ', '').split('(')[0].replace('fep::', '')
+
+
+def kernel_stats(d):
+    """[(name, calls, total_ns, avg_ns, pct, min_ns, max_ns)] of one --stats pass."""
+    rows = []
+    for f in glob.glob(os.path.join(d, '*', '*_kernel_stats.csv')):
+        for r in csv.DictReader(open(f)):
+            rows.append((short(r['Name']), int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']),
+                         float(r['Percentage']), float(r['MinNs']), float(r['MaxNs'])))
+    for f in glob.glob(os.path.join(d, '*', '*.db')):
+        c = sqlite3.connect(f)
+        tot = c.execute('select sum(duration) from kernels').fetchone()[0] or 1.0
+        for name, n, t, a, lo, hi in c.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
+                                               'from kernels group by name order by sum(duration) desc'):
+            rows.append((short(name), n, float(t), float(a), 100.0 * t / tot, float(lo), float(hi)))
+    return rows
+
+
+def counters(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, '*', '*_counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    for f in glob.glob(os.path.join(d, '*', '*.db')):
+        c = sqlite3.connect(f)
+        # one row per (dispatch, counter, dimension instance): sum the instances of a dispatch, average over dispatches
+        q = ('select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection '
+             'group by kernel_name, counter_name, dispatch_id')
+        for k, cn, _, v in c.execute(q):
+            acc[short(k)][cn].append(float(v))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def main():
+    tag, base = sys.argv[1:3]
+    out = os.path.join(ROOT, 'profiles')
+    rows = kernel_stats(os.path.join(base, 'stats'))
+    with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for r in rows:
+            w.writerow([r[0], r[1], f'{r[2]:.0f}', f'{r[3]:.0f}', f'{r[4]:.2f}', f'{r[5]:.0f}', f'{r[6]:.0f}'])
+    avg = {r[0]: r[3] for r in rows}
+    allc = collections.defaultdict(dict)
+    for sub in ('fetch', 'write', 'sq', 'sq2'):
+        for k, cs in counters(os.path.join(base, sub)).items():
+            allc[k].update(cs)
+    names = sorted({c for cs in allc.values() for c in cs})
+    with open(os.path.join(out, f'{tag}_counters.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['kernel', 'avg_us', 'hbm_bytes_per_launch=(2*FETCH_SIZE+WRITE_SIZE)KiB*1024', 'GBps_on_those_bytes'] + names)
+        for k in sorted(allc, key=lambda k: -avg.get(k, 0.0)):
+            if 'kernel' not in k or k.startswith('at::') or 'elementwise' in k or k.startswith('__amd'):
+                continue
+            cs = allc[k]
+            b = (2 * cs.get('FETCH_SIZE', 0.0) + cs.get('WRITE_SIZE', 0.0)) * 1024
+            us = avg.get(k, 0.0) / 1e3
+            w.writerow([k, f'{us:.2f}', f'{b:.0f}', f'{b / us / 1e3:.0f}' if us else ''] + [f'{cs.get(c, float("nan")):.0f}' for c in names])
+            valu = cs.get('SQ_ACTIVE_INST_VALU', float('nan')) / max(cs.get('SQ_BUSY_CYCLES', float('nan')), 1.0)
+            print(f'{k[:60]:60s} {us:9.1f} us  {b / 1e6:9.1f} MB  ' + (f'{b / us / 1e3:6.0f} GB/s' if us else '') +
+                  f'  VALU-active/busy {valu:.2f}')
+
+
+if __name__ == '__main__':
+    main()
