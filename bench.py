@@ -51,16 +51,21 @@ def dp_materials():
             3 * np.tan(phi) / np.sqrt(9 + 12 * np.tan(phi) ** 2), 3 * c0 / np.sqrt(9 + 12 * np.tan(phi) ** 2))
 
 
-def displacement(coord, seed=1, scale=1.0):
-    """Synthetic state on the GLOBAL node set: shear/compression bands + noise, periodic in y with the strip
-    height.  `scale` multiplies the smooth part (scale 1: ~18 % smooth / 57 % apex points; see --field-scale)."""
+def displacement(coord, seed=1, scale=1.0, state='bands'):
+    """Synthetic state on the GLOBAL node set, periodic in y with the strip height, + noise.
+    'bands'  (default) shear / compression / tension bands: ~18 % smooth and ~57 % apex points;
+    'newton' a branch mix like the Newton iterates of configs[3] (tools/newton_bench.py: ~30 % smooth, < 0.1 % apex):
+             slight uniform compression with a strong shear in the strip x < 3 (29 % smooth, no apex point)."""
     x, y = coord[0], np.mod(coord[1], 10.0)
-    U = scale * np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    if state == 'newton':
+        U = scale * np.array([np.where(x < 3.0, 4.0e-4, 0.8e-4) * y, -2.0e-5 * y])
+    else:
+        U = scale * np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
     U += np.random.default_rng(seed).normal(0, 2e-8, size=U.shape)
     return U
 
 
-def cpu_baseline(fep, elem_type='P1', n_cells=N_CELLS, repeats=3, scale=1.0):
+def cpu_baseline(fep, elem_type='P1', n_cells=N_CELLS, repeats=3, scale=1.0, state='bands'):
     """The oracle (NumPy/SciPy restatement of the reference path) on the same workload (same mesh, field and
     materials), 1 host thread."""
     from oracle import fep_oracle as orc
@@ -72,7 +77,7 @@ def cpu_baseline(fep, elem_type='P1', n_cells=N_CELLS, repeats=3, scale=1.0):
     one = np.ones(n_int)
     K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, G * one, Kb * one, d1, d2, wf)
     ctx = dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=G * one, bulk=Kb * one, eta=eta * one, c=c * one)
-    U = displacement(coord, scale=scale)
+    U = displacement(coord, scale=scale, state=state)
     Ep = np.zeros((4, n_int))
     best = float('inf')
     for _ in range(repeats):
@@ -92,9 +97,10 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cells', type=int, default=N_CELLS, help='cells per side of the square (per GPU when weak)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
-    ap.add_argument('--field-scale', type=float, default=1.0,
-                    help='multiplies the displacement field (0.35: ~30 %% smooth, no apex points, like the Newton '
-                         'iterates of configs[3])')
+    ap.add_argument('--field-scale', type=float, default=1.0, help='multiplies the displacement field')
+    ap.add_argument('--state', choices=('bands', 'newton'), default='bands',
+                    help="branch mix of the synthetic state: 'bands' ~18 %% smooth / 57 %% apex (default), 'newton' ~29 %% "
+                         "smooth / no apex, like the Newton iterates of configs[3]")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-cells', type=int, default=None, help='cells per side of the CPU-baseline square (default: --cells)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
@@ -119,13 +125,13 @@ def launch_ranks(n):
 class Shard:
     """One rank's part of a mesh: device context + device-resident state of the benchmark step."""
 
-    def __init__(self, fep, torch, mesh, rank, world, dev, scale, two_buffers):
+    def __init__(self, fep, torch, mesh, rank, world, dev, scale, two_buffers, state='bands'):
         self.sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=dev.index)
         ctx = self.ctx = self.sh.ctx
         ctx.set_materials(*dp_materials())
         n_int = self.n_int = ctx.n_int
         # the field is a function of the GLOBAL node set (identical on every rank that shares a node)
-        U_h = displacement(mesh['coordinates'], scale=scale)[:, self.sh.nodes]
+        U_h = displacement(mesh['coordinates'], scale=scale, state=state)[:, self.sh.nodes]
         f64 = dict(dtype=torch.float64, device=dev)
         self.U = torch.from_numpy(np.ascontiguousarray(U_h.reshape(-1, order='F'))).to(dev)
         self.Ep = torch.zeros((4, n_int), **f64)
@@ -245,7 +251,7 @@ def run(args):
     # ---- the headline run ------------------------------------------------------------------------------------
     strong = args.scaling == 'strong'
     mesh = fep.rect_mesh(N, N if strong else N * world, 'P1', 10, 10 if strong else 10 * world)
-    shard = Shard(fep, torch, mesh, rank, world, dev, args.field_scale, world > 1)
+    shard = Shard(fep, torch, mesh, rank, world, dev, args.field_scale, world > 1, args.state)
     n_total = int(mesh['elements'].shape[1])
     dt, step = timed(shard, args.steps, args.warmup)
     cnt = shard.counts.clone()
@@ -271,7 +277,7 @@ def run(args):
     strong_line = None
     if world > 1 and not strong:
         mesh_s = fep.rect_mesh(N, N, 'P1', 10, 10)
-        shard_s = Shard(fep, torch, mesh_s, rank, world, dev, args.field_scale, True)
+        shard_s = Shard(fep, torch, mesh_s, rank, world, dev, args.field_scale, True, args.state)
         dt_s, step_s = timed(shard_s, args.steps, args.warmup)
         kms_s, _ = per_kernel(shard_s, step_s, args.steps)
         rk = gather_ranks([kms_s['element'], kms_s['csr'], float(shard_s.n_int)])
@@ -317,7 +323,7 @@ def run(args):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('elements_per_gpu', 1002528) == n_int and route == 'node' and args.field_scale == 1.0:
+                if tj.get('elements_per_gpu', 1002528) == n_int and route == 'node' and args.field_scale == 1.0 and args.state == 'bands':
                     traffic = tj.get('hbm_bytes_per_launch')
                     traffic_source = ('profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
                                       '`python bench.py`, 2*FETCH + WRITE per the gfx950 correction; not measured in this run)')
@@ -337,7 +343,7 @@ def run(args):
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wl + ', Drucker-Prager, strain->return map->K_tan CSR values->F per step',
                        'elements_per_gpu': n_int, 'elements_total': n_total, 'nnz_per_gpu': ctx.nnz,
-                       'smooth_points': n_smooth, 'apex_points': n_apex, 'field_scale': args.field_scale,
+                       'smooth_points': n_smooth, 'apex_points': n_apex, 'field_scale': args.field_scale, 'state': args.state,
                        'route': route,
                        'parallelism': f'element-shard x{world}, interface-force all-reduce' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -354,7 +360,7 @@ def run(args):
         if kf:
             line['kf_only'] = kf
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(fep, n_cells=args.cpu_cells or N, scale=args.field_scale)
+            line['cpu_baseline'] = cpu_baseline(fep, n_cells=args.cpu_cells or N, scale=args.field_scale, state=args.state)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

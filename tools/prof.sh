@@ -5,6 +5,8 @@
 # --pmc is never combined with the runtime trace domains).
 set -e
 tag=$1; shift
+extra=""
+if [ "$1" == "--traffic-latest" ]; then extra="--traffic-latest"; shift; fi
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -13,4 +15,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -- "$@" > $out/fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -- "$@" > $out/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY -d $out/sq -- "$@" > $out/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $out/sq2 -- "$@" > $out/sq2.log 2>&1
-python3 tools/summarize_counters.py $tag $out
+python3 tools/summarize_counters.py $tag $out $extra

@@ -50,6 +50,7 @@ def counters(d):
 
 def main():
     tag, base = sys.argv[1:3]
+    latest = '--traffic-latest' in sys.argv          # this run is `bench.py` at its default size: refresh traffic_latest.json
     out = os.path.join(ROOT, 'profiles')
     rows = kernel_stats(os.path.join(base, 'stats'))
     with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w', newline='') as fh:
@@ -76,6 +77,15 @@ def main():
             valu = cs.get('SQ_ACTIVE_INST_VALU', float('nan')) / max(cs.get('SQ_BUSY_CYCLES', float('nan')), 1.0)
             print(f'{k[:60]:60s} {us:9.1f} us  {b / 1e6:9.1f} MB  ' + (f'{b / us / 1e3:6.0f} GB/s' if us else '') +
                   f'  VALU-active/busy {valu:.2f}')
+    if latest:
+        import json
+        hb = {k: (2 * cs.get('FETCH_SIZE', 0.0) + cs.get('WRITE_SIZE', 0.0)) * 1024 for k, cs in allc.items()}
+        dom = [k for k in hb if k.startswith('p1_point_kernel') or k.startswith('p1_node_lds_kernel')]
+        json.dump({'round': tag, 'kernels': {k: hb[k] for k in dom}, 'hbm_bytes_per_launch': sum(hb[k] for k in dom),
+                   'kf_only_kernel': {k: hb[k] for k in hb if k.startswith('p1_fused_kernel')},
+                   'note': 'full-output step = p1_point_kernel + p1_node_lds_kernel; 2*FETCH_SIZE + WRITE_SIZE (KiB) * 1024, '
+                           'separate rocprofv3 --pmc passes of `python3 bench.py --steps 10 --no-cpu-baseline` (tools/prof.sh)',
+                   'elements_per_gpu': 1002528}, open(os.path.join(out, 'traffic_latest.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
