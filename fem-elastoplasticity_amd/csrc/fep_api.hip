@@ -49,6 +49,7 @@ struct fep_ctx {
     int n_wg_p1 = 0;   // LDS-staged variant: per-workgroup element lists
     // one-kernel step (p1_fused_kernel): per-tile node lists / runs, per staged element its tile-local node indices + owner bit
     bool p1_fused = false, p1_fused_rng = false;
+    bool asm_from_nodes = false;                        // FEP_P1_ASM=nodes: assembly kernel with geometry from LDS-staged nodes (measured slower)
     int fused_mode = 1;                                 // FEP_P1_FUSED=off|kf|all: 0 = never, 1 = only when no point output is wanted (default), 2 = always
     int lds_NL = 0;                                     // staged nodes per tile (max)
     int32_t *wg_nlist = nullptr, *wg_nrng = nullptr;
@@ -422,6 +423,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
             c->n_wg_p1 = (int)P.n_wg; c->p1_segs = P.n_segs;
             c->p1_lds = P.lds; c->lds_L = P.L; c->lds_C = P.C; c->p1_rng = P.rng; c->p1_pk = P.pk;
             c->p1_fused = P.fused; c->p1_fused_rng = P.fused_rng; c->lds_NL = P.NL;
+            if (const char* am = std::getenv("FEP_P1_ASM")) c->asm_from_nodes = std::strcmp(am, "nodes") == 0;
             if (const char* fm = std::getenv("FEP_P1_FUSED"))
                 c->fused_mode = std::strcmp(fm, "off") == 0 ? 0 : std::strcmp(fm, "kf") == 0 ? 1 : 2;
             CK(upload(&c->perm2, P.perm2.data(), (int64_t)P.perm2.size()));
@@ -660,7 +662,34 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
     FEP_TRY(prof_mark(c, st));
     if (counts_done) *counts_done = false;
     if ((k_data && ds) || (f_out && s)) {
-        if (c->p1_lds) {
+        if (c->p1_fused && c->asm_from_nodes) {
+            // opt-in (FEP_P1_ASM=nodes): assembly-only form of the one-kernel step, geometry from the tile's LDS-staged nodes
+            // instead of the 48-byte record per staged element (same values bit for bit; 25 % fewer bytes but one barrier
+            // and the geometry arithmetic more: 72.0 against 66.4 us at 1 M elements, profiles/r02_ablation.md)
+            const size_t lds_stage = (((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 + 15) & ~(size_t)15) +
+                                     (size_t)c->lds_NL * 2 * sizeof(double2);
+            const size_t lds = std::max(lds_stage, (size_t)c->tile * 3 * sizeof(double2));
+            const int n_wg = c->n_wg_p1;
+            const int chunk = (n_wg + 7) / 8;
+#define ASM4(RNG, EPT, NPT)                                                                                              \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_fused_kernel<false, 256, RNG, EPT, NPT, true>,                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+        hipLaunchKernelGGL((p1_fused_kernel<false, 256, RNG, EPT, NPT, true>), dim3(8 * chunk), dim3(256), lds, st,      \
+                           c->n_e, c->lds_L, c->lds_C, c->lds_NL, c->perm_l, c->wg_elist, (const int4*)c->wg_rng,        \
+                           c->wg_nlist, (const int4*)c->wg_nrng, c->el_nodes, c->pk, c->tdesc, c->xy, c->p1tab,          \
+                           (const double*)nullptr, make_e0(nullptr), (const double*)nullptr, c->shear, c->bulk, c->eta,  \
+                           c->c, c->matu, (double*)nullptr, (double*)nullptr, (double*)nullptr, (uint8_t*)nullptr,       \
+                           k_data, f_out, n_wg, (unsigned long long*)nullptr, k_data ? ds : (const double*)nullptr,      \
+                           f_out ? s : (const double*)nullptr, c->n_count_blocks, c->blk_counts, counts_d);              \
+    } while (0)
+            const bool e1 = c->lds_L <= 256, n1 = c->lds_NL <= 256;
+            if (c->p1_fused_rng) { if (e1 && n1) ASM4(true, 1, 1); else if (e1) ASM4(true, 1, 2); else if (n1) ASM4(true, 2, 1); else ASM4(true, 2, 2); }
+            else { if (e1 && n1) ASM4(false, 1, 1); else if (e1) ASM4(false, 1, 2); else if (n1) ASM4(false, 2, 1); else ASM4(false, 2, 2); }
+#undef ASM4
+            if (counts_done) *counts_done = counts_d != nullptr;
+        } else if (c->p1_lds) {
             // operands + codes while gathering, then the same LDS holds the tile's output (4*TPB values + forces)
             const size_t lds = std::max((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t),
                                         (size_t)c->tile * 3 * sizeof(double2));
@@ -771,7 +800,9 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
                            c->n_e, c->lds_L, c->lds_C, c->lds_NL, c->perm_l, c->wg_elist, (const int4*)c->wg_rng,        \
                            c->wg_nlist, (const int4*)c->wg_nrng, c->el_nodes, c->pk, c->tdesc, c->xy,                   \
                            c->p1tab, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu, eout, s, ds, indp, k_data,      \
-                           f_out, n_wg, counts_d ? c->slot_counts : (unsigned long long*)nullptr);                       \
+                           f_out, n_wg, counts_d ? c->slot_counts : (unsigned long long*)nullptr,                        \
+                           (const double*)nullptr, (const double*)nullptr, 0, (const uint2*)nullptr,                     \
+                           (unsigned long long*)nullptr);                                                                \
     } while (0)
 #define FUSED3(FULL, RNG) do {                                                                                           \
         const bool e1 = c->lds_L <= 256, n1 = c->lds_NL <= 256;                                                          \

@@ -906,7 +906,10 @@ p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr
 // Accepting calls (plastic strain updated in place) keep the two-kernel route: a neighbour tile could otherwise
 // read an element's updated plastic strain.
 // ---------------------------------------------------------------------------------------
-template <bool FULL, int TPB, bool RNG, int EPT, int NPT>
+// FROM_DS = true: the assembly-only form (fep_assemble_dev, and the second kernel of a full-output / accepting step):
+// w*DS and w*s come from the caller's ds / s arrays (`DSin`, `Sin`) instead of the return map, the geometry still from
+// the tile's LDS-staged nodes — 48 bytes per staged element less to fetch than p1_node_lds_kernel's geometry record.
+template <bool FULL, int TPB, bool RNG, int EPT, int NPT, bool FROM_DS = false>
 __global__ void __launch_bounds__(TPB, (!FULL && EPT == 1) ? 8 : 1)     // K/F-only: 64 VGPRs, 8 tiles of 4 waves per CU
 p1_fused_kernel(int64_t n_e, int L, int C, int NL,
                 const uint16_t* __restrict__ perm_l, const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
@@ -917,8 +920,13 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
                 const double* __restrict__ shear, const double* __restrict__ bulk,
                 const double* __restrict__ eta, const double* __restrict__ cc, MatU mu,
                 double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
-                double* __restrict__ data, double* __restrict__ F, int n_wg, unsigned long long* __restrict__ slot_counts) {
+                double* __restrict__ data, double* __restrict__ F, int n_wg, unsigned long long* __restrict__ slot_counts,
+                const double* __restrict__ DSin, const double* __restrict__ Sin,
+                int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
+    static_assert(!(FULL && FROM_DS), "the assembly-only form has no point outputs");
     extern __shared__ __attribute__((aligned(16))) double rec[];      // [15][L] | codes | node coordinates | node displacements
+    // assembly-only form after p1_point_kernel: the first workgroup also sums that kernel's per-workgroup branch counters
+    if (FROM_DS && counts_out != nullptr && blockIdx.x == 0) sum_block_counts(n_count_blocks, blk_counts, counts_out);
     __shared__ unsigned int sc[2];
     const int chunk = (n_wg + 7) >> 3;                                // XCD-aware tile order (see p1_node_lds_kernel)
     const int wg = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
@@ -976,19 +984,28 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
     for (int r = 0; r < NPT; ++r) {
         if (r * TPB + (int)(threadIdx.x & ~63u) >= n_nd) continue;   // wave-uniform: idle waves issue nothing
         nxy[r] = *reinterpret_cast<const double2*>(xy + 2 * nd[r]);
-        nu[r] = *reinterpret_cast<const double2*>(U + 2 * nd[r]);
+        if (!FROM_DS) nu[r] = *reinterpret_cast<const double2*>(U + 2 * nd[r]);
     }
     uint32_t enw[EPT];
     double pv[EPT][4], mv[EPT][4];
+    double dvi[EPT][6], svi[EPT][3];                    // FROM_DS: the caller's tangent / stress of the staged elements
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         if (r * TPB + (int)(threadIdx.x & ~63u) >= n_el) continue;
         const int i = r * TPB + (int)threadIdx.x;
         const int64_t e = el[r];
         enw[r] = el_nodes[(int64_t)wg * L + (i < L ? i : 0)];
-        if (ep) { pv[r][0] = ep[e]; pv[r][1] = ep[n_e + e]; pv[r][2] = ep[2 * n_e + e]; pv[r][3] = ep[3 * n_e + e]; }
-        else { pv[r][0] = 0.0; pv[r][1] = 0.0; pv[r][2] = 0.0; pv[r][3] = 0.0; }
-        if (!mu.on) { mv[r][0] = shear[e]; mv[r][1] = bulk[e]; mv[r][2] = eta[e]; mv[r][3] = cc[e]; }
+        if (FROM_DS) {
+            if (DSin) {
+                dvi[r][0] = DSin[e]; dvi[r][1] = DSin[n_e + e]; dvi[r][2] = DSin[2 * n_e + e];
+                dvi[r][3] = DSin[4 * n_e + e]; dvi[r][4] = DSin[5 * n_e + e]; dvi[r][5] = DSin[8 * n_e + e];
+            }
+            if (Sin) { svi[r][0] = Sin[e]; svi[r][1] = Sin[n_e + e]; svi[r][2] = Sin[2 * n_e + e]; }
+        } else {
+            if (ep) { pv[r][0] = ep[e]; pv[r][1] = ep[n_e + e]; pv[r][2] = ep[2 * n_e + e]; pv[r][3] = ep[3 * n_e + e]; }
+            else { pv[r][0] = 0.0; pv[r][1] = 0.0; pv[r][2] = 0.0; pv[r][3] = 0.0; }
+            if (!mu.on) { mv[r][0] = shear[e]; mv[r][1] = bulk[e]; mv[r][2] = eta[e]; mv[r][3] = cc[e]; }
+        }
     }
     // (3) the lane's block descriptor and the tile's gather codes (consumed last)
     const uint2 w2 = live ? pk[sb] : make_uint2(0u, 0u);
@@ -1009,7 +1026,7 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
 #pragma unroll
     for (int r = 0; r < NPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
-        if (i < n_nd) { lxy[i] = nxy[r]; lu[i] = nu[r]; }
+        if (i < n_nd) { lxy[i] = nxy[r]; if (!FROM_DS) lu[i] = nu[r]; }
     }
 #pragma unroll
     for (int q = 0; q < CWPT; ++q) {
@@ -1030,21 +1047,27 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
             own = (wv >> 30) & 1u;
             const int i0 = (int)(wv & 1023u), i1 = (int)((wv >> 10) & 1023u), i2 = (int)((wv >> 20) & 1023u);
             const double2 c0 = lxy[i0], c1 = lxy[i1], c2 = lxy[i2];
-            const double2 u0 = lu[i0], u1 = lu[i1], u2 = lu[i2];
             double d1[3], d2[3], w;
             p1_geometry(tab, c0, c1, c2, d1, d2, w);
-            double ev[3];                                            // DP:1043, local node order
-            ev[0] = d1[0] * u0.x + d1[1] * u1.x + d1[2] * u2.x;
-            ev[1] = d2[0] * u0.y + d2[1] * u1.y + d2[2] * u2.y;
-            ev[2] = (d2[0] * u0.x + d1[0] * u0.y) + (d2[1] * u1.x + d1[1] * u1.y) + (d2[2] * u2.x + d1[2] * u2.y);
-            double p[4] = {pv[r][0], pv[r][1], pv[r][2], pv[r][3]};
             double s[4], d[6];
-            const double m_sh = mu.on ? mu.shear : mv[r][0], m_bu = mu.on ? mu.bulk : mv[r][1];
-            const double m_eta = mu.on ? mu.eta : mv[r][2], m_c = mu.on ? mu.c : mv[r][3];
-            branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, false, s, d);
-            if (FULL && own) {
-                store_point(e, n_e, s, d, branch, S, DS, indp);
-                if (Eout) { Eout[e] = ev[0]; Eout[n_e + e] = ev[1]; Eout[2 * n_e + e] = ev[2]; }
+            if (FROM_DS) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d[k] = DSin ? dvi[r][k] : 0.0;
+                s[0] = Sin ? svi[r][0] : 0.0; s[1] = Sin ? svi[r][1] : 0.0; s[2] = Sin ? svi[r][2] : 0.0;
+            } else {
+                const double2 u0 = lu[i0], u1 = lu[i1], u2 = lu[i2];
+                double ev[3];                                            // DP:1043, local node order
+                ev[0] = d1[0] * u0.x + d1[1] * u1.x + d1[2] * u2.x;
+                ev[1] = d2[0] * u0.y + d2[1] * u1.y + d2[2] * u2.y;
+                ev[2] = (d2[0] * u0.x + d1[0] * u0.y) + (d2[1] * u1.x + d1[1] * u1.y) + (d2[2] * u2.x + d1[2] * u2.y);
+                double p[4] = {pv[r][0], pv[r][1], pv[r][2], pv[r][3]};
+                const double m_sh = mu.on ? mu.shear : mv[r][0], m_bu = mu.on ? mu.bulk : mv[r][1];
+                const double m_eta = mu.on ? mu.eta : mv[r][2], m_c = mu.on ? mu.c : mv[r][3];
+                branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, false, s, d);
+                if (FULL && own) {
+                    store_point(e, n_e, s, d, branch, S, DS, indp);
+                    if (Eout) { Eout[e] = ev[0]; Eout[n_e + e] = ev[1]; Eout[2 * n_e + e] = ev[2]; }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) rec[k * L + i] = w * d[k];

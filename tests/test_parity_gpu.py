@@ -229,6 +229,26 @@ def test_p1_fused_step_is_bitwise_the_two_kernel_route(fep, monkeypatch, name):
     assert np.array_equal(a[0]['K'].data, a[2]['K'].data)
 
 
+def test_p1_assembly_from_staged_nodes_is_bitwise_the_record_form(fep, monkeypatch):
+    """FEP_P1_ASM=nodes: the assembly kernel takes its geometry from the tile's LDS-staged nodes instead of the 48-byte
+    records; same K, F bit for bit (full-output step, accepting step, assemble_tangent)."""
+    elem, coord, mats, U, Ep, e0 = _p1_case(fep, 'square150')
+    res = []
+    for mode in ('record', 'nodes'):
+        monkeypatch.setenv('FEP_P1_ASM', mode)
+        ctx = fep.MeshContext(elem, coord)
+        ctx.set_materials(*mats)
+        ep = Ep.copy()
+        full = ctx.step(U, ep, want=('s', 'ds', 'K', 'F'))
+        acc = ctx.step(U, ep, apply_plastic_strain=True, want=('K', 'F'))
+        K2, F2 = ctx.assemble(full['ds'], full['s'])
+        _, F3 = ctx.assemble(None, full['s'])
+        res.append((full['K'].data, full['F'], acc['K'].data, acc['F'], K2.data, F2, F3, full['n_smooth'], acc['n_apex']))
+        ctx.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
     """A node that belongs to no element has no block in K and no lane that writes its force: F must still come back
     as zero there on every route (the reference's B^T product gives 0), not as uninitialised memory."""
