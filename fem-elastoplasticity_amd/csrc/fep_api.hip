@@ -25,6 +25,9 @@ struct fep_ctx {
     int n_p = 0, n_q = 0;
     int64_t n_e = 0, n_n = 0, n_int = 0, n_dof = 0, nnz = 0, n_blk = 0, n_contrib = 0;
     bool have_materials = false;
+    int csr_gathers = 4;                                // gathers in flight per lane of csr_reduce_kernel (FEP_CSR_GATHERS=2|4|6|8;
+                                                        // measured P2 / Q2 / P4 reduce kernel: 2: 0.406 / 0.376 / 0.654 ms, 4: 0.392 / 0.347 / 0.651,
+                                                        // 6: 0.382 / 0.371 / 0.650, 8 (5 waves per SIMD): 0.432 / 0.425 / 0.733)
     bool kc_aos = false;                                // K_e half-blocks: all blocks of an element adjacent (AoS) or block-major (SoA)
     bool elem_geo = true;                               // element_kernel: geometry from coordinates instead of the dphi arrays
     MatU matu{};                                        // homogeneous-material fast path (arrays not read)
@@ -492,6 +495,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         // (P4: step 1.47 -> 1.35 ms; P2 0.96 -> 1.06, Q2 0.82 -> 0.94, Q1 0.22 -> 0.26: their stores lose coalescing)
         c->kc_aos = elem_type == FEP_P4;
         if (const char* kl = std::getenv("FEP_KC_LAYOUT")) c->kc_aos = std::strcmp(kl, "aos") == 0;
+        if (const char* cg = std::getenv("FEP_CSR_GATHERS")) c->csr_gathers = std::atoi(cg);
         if ((int64_t)sym_block_count(n_p) * n_e >= (int64_t)1 << 30) r = FEP_ERANGE;     // 2 * position fits int32
         {   // element_kernel stores half of the symmetric K_e: re-address the contributions (block, transposed)
             std::vector<int32_t> perm_sym(S.perm.size());
@@ -638,9 +642,18 @@ static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_o
     if (counts_done) *counts_done = false;
     FEP_TRY(prof_mark(c, st));
     if (k_data) {
-        hipLaunchKernelGGL(csr_reduce_kernel, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st,
-                           c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data, c->n_count_blocks,
-                           c->blk_counts, counts_d);
+#define CSR_REDUCE(G)                                                                                                    \
+    hipLaunchKernelGGL(csr_reduce_kernel<G>, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st,                 \
+                       c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data, c->n_count_blocks,             \
+                       c->blk_counts, counts_d)
+        switch (c->csr_gathers) {
+            case 2: CSR_REDUCE(2); break;
+            case 4: CSR_REDUCE(4); break;
+            case 6: CSR_REDUCE(6); break;
+            case 8: CSR_REDUCE(8); break;
+            default: CSR_REDUCE(4); break;
+        }
+#undef CSR_REDUCE
         HIP_TRY(hipGetLastError());
         if (counts_done) *counts_done = counts_d != nullptr;
     }

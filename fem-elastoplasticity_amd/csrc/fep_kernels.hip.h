@@ -441,6 +441,11 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 //   meta[blk] = (deg(n) << 16) | (diag << 15) | s
 //   CSR data: row 2n+i starts at 4*nptr[n] + i*2*deg, entry (slot s, comp j) at + 2s + j.
 // ---------------------------------------------------------------------------------------
+// G = gathers in flight per lane: the lane's contributions are fetched G at a time — first their G addresses
+// (independent loads: the segment bounds are known), then the G 32-byte blocks, then summed in list order (the
+// summation order does not depend on G).  The kernel is a chain of dependent gathers (86 % of its wave cycles sit in
+// s_waitcnt with every wave slot taken): rounds per lane, not bytes, set its time.
+template <int G>
 __global__ void __launch_bounds__(kBlock)
 csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t* __restrict__ segptr,
                   const int32_t* __restrict__ perm, const uint32_t* __restrict__ meta,
@@ -462,22 +467,25 @@ csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t
         const int32_t beg = segptr[sb], end = segptr[sb + 1];
         const uint32_t m = meta[sb];
         double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-        int32_t t = beg;
-        for (; t + 1 < end; t += 2) {                           // two gathers in flight; summation order unchanged
-            const int32_t pv = perm[t], pw = perm[t + 1];       // (stored block index) * 2 + transposed
-            const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(pv >> 1) * 4);
-            const double2* srd = reinterpret_cast<const double2*>(Kc + (int64_t)(pw >> 1) * 4);
-            const double2 r0 = src[0], r1 = src[1], q0 = srd[0], q1 = srd[1];
-            const bool tr = pv & 1, tq = pw & 1;
-            a00 += r0.x; a01 += tr ? r1.x : r0.y; a10 += tr ? r0.y : r1.x; a11 += r1.y;
-            a00 += q0.x; a01 += tq ? q1.x : q0.y; a10 += tq ? q0.y : q1.x; a11 += q1.y;
-        }
-        if (t < end) {
-            const int32_t pv = perm[t];
-            const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(pv >> 1) * 4);
-            const double2 r0 = src[0], r1 = src[1];
-            const bool tr = pv & 1;
-            a00 += r0.x; a01 += tr ? r1.x : r0.y; a10 += tr ? r0.y : r1.x; a11 += r1.y;
+        for (int32_t t = beg; t < end; t += G) {
+            int32_t pv[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) pv[k] = t + k < end ? perm[t + k] : -1;     // (stored block index) * 2 + transposed
+            double2 r0[G], r1[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if (pv[k] >= 0) {
+                    const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(pv[k] >> 1) * 4);
+                    r0[k] = src[0]; r1[k] = src[1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if (pv[k] >= 0) {
+                    const bool tr = pv[k] & 1;
+                    a00 += r0[k].x; a01 += tr ? r1[k].x : r0[k].y; a10 += tr ? r0[k].y : r1[k].x; a11 += r1[k].y;
+                }
+            }
         }
         const int sl = (int)(m & 0x7fffu), deg = (int)(m >> 16);
         const int rel = 2 * (int)threadIdx.x - sl;          // (CSR position - 4*sb0) / 2
