@@ -25,6 +25,7 @@ struct fep_ctx {
     int n_p = 0, n_q = 0;
     int64_t n_e = 0, n_n = 0, n_int = 0, n_dof = 0, nnz = 0, n_blk = 0, n_contrib = 0;
     bool have_materials = false;
+    uint2* pkc = nullptr;                               // COO route: packed block descriptors of csr_reduce_pk_kernel (NULL: fields too wide)
     int csr_gathers = 4;                                // gathers in flight per lane of csr_reduce_kernel (FEP_CSR_GATHERS=2|4|6|8;
                                                         // measured P2 / Q2 / P4 reduce kernel: 2: 0.406 / 0.376 / 0.654 ms, 4: 0.392 / 0.347 / 0.651,
                                                         // 6: 0.382 / 0.371 / 0.650, 8 (5 waves per SIMD): 0.432 / 0.425 / 0.733)
@@ -318,7 +319,7 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
                         c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tdesc, c->tstart,
-                        c->wg_nlist, c->wg_nrng, c->el_nodes, c->slot_counts};
+                        c->wg_nlist, c->wg_nrng, c->el_nodes, c->slot_counts, c->pkc};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -508,7 +509,17 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 const int64_t pos = c->kc_aos ? e * sym_block_count(n_p) + idx : (int64_t)idx * n_e + e;
                 perm_sym[i] = (int32_t)(2 * pos + (tr ? 1 : 0));
             }
+            perm_sym.resize(perm_sym.size() + 4, 0);                    // csr_reduce_pk_kernel reads the addresses four at a time
             CK(upload(&c->perm, perm_sym.data(), (int64_t)perm_sym.size()));
+            // one 8-byte descriptor per block, if its fields fit (count < 256, degree and slot < 4096)
+            std::vector<uint2> pkc((size_t)c->n_blk);
+            bool fits = std::getenv("FEP_CSR_UNPACKED") == nullptr;
+            for (int64_t b = 0; b < c->n_blk && fits; ++b) {
+                const uint32_t len = (uint32_t)(S.segptr[b + 1] - S.segptr[b]), deg = S.meta[b] >> 16, slot = S.meta[b] & 0x7fffu;
+                fits = len < 256 && deg < 4096 && slot < 4096;
+                pkc[b] = make_uint2((uint32_t)S.segptr[b], len | (deg << 8) | (slot << 20));
+            }
+            if (fits) CK(upload(&c->pkc, pkc.data(), (int64_t)pkc.size()));
         }
         CK(upload(&c->tstart, tstart_all.data(), (int64_t)tstart_all.size()));
         c->n_wg_p1 = (int)tstart_all.size() - 1;
@@ -646,6 +657,10 @@ static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_o
     hipLaunchKernelGGL(csr_reduce_kernel<G>, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st,                 \
                        c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data, c->n_count_blocks,             \
                        c->blk_counts, counts_d)
+        if (c->pkc)
+            hipLaunchKernelGGL(csr_reduce_pk_kernel, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st, c->n_wg_p1,
+                               c->tstart, c->pkc, c->perm, c->Kc, k_data, c->n_count_blocks, c->blk_counts, counts_d);
+        else
         switch (c->csr_gathers) {
             case 2: CSR_REDUCE(2); break;
             case 4: CSR_REDUCE(4); break;

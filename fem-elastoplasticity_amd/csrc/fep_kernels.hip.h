@@ -497,6 +497,54 @@ csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t
     for (int i = threadIdx.x; i < 2 * nb; i += kBlock) dst[i] = out2[i];
 }
 
+// The same reduce with fewer vector-memory instructions per lane (its time follows their count): ONE 8-byte descriptor
+// per block (x: first contribution, y: count:8 | degree:12 | slot:12) instead of segptr x2 + meta, and the lane's
+// contribution addresses four at a time with one 16-byte load (`perm` is padded by 4 entries; the load needs 4-byte
+// alignment only).  Same adds in the same order.
+struct __attribute__((packed, aligned(4))) PermQuad { int32_t v[4]; };
+
+__global__ void __launch_bounds__(kBlock)
+csr_reduce_pk_kernel(int n_tiles, const int32_t* __restrict__ tstart, const uint2* __restrict__ pkc,
+                     const int32_t* __restrict__ perm, const double* __restrict__ Kc, double* __restrict__ data,
+                     int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
+    __shared__ double2 out2[2 * kBlock];
+    const int g = counts_out != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (g < 0) { sum_block_counts(n_count_blocks, blk_counts, counts_out); return; }
+    if (g >= n_tiles) return;
+    const int64_t sb0 = tstart[g];
+    const int nb = tstart[g + 1] - (int)sb0;
+    if ((int)threadIdx.x < nb) {
+        const uint2 d = pkc[sb0 + threadIdx.x];
+        const int32_t* pl = perm + d.x;
+        const int len = (int)(d.y & 255u), deg = (int)((d.y >> 8) & 4095u), sl = (int)(d.y >> 20);
+        double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+        for (int t = 0; t < len; t += 4) {
+            const PermQuad q = *reinterpret_cast<const PermQuad*>(pl + t);
+            double2 r0[4], r1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (t + k < len) {
+                    const double2* src = reinterpret_cast<const double2*>(Kc + (int64_t)(q.v[k] >> 1) * 4);
+                    r0[k] = src[0]; r1[k] = src[1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (t + k < len) {
+                    const bool tr = q.v[k] & 1;
+                    a00 += r0[k].x; a01 += tr ? r1[k].x : r0[k].y; a10 += tr ? r0[k].y : r1[k].x; a11 += r1[k].y;
+                }
+            }
+        }
+        const int rel = 2 * (int)threadIdx.x - sl;
+        out2[rel] = make_double2(a00, a01);
+        out2[rel + deg] = make_double2(a10, a11);
+    }
+    __syncthreads();
+    double2* dst = reinterpret_cast<double2*>(data + 4 * sb0);
+    for (int i = threadIdx.x; i < 2 * nb; i += kBlock) dst[i] = out2[i];
+}
+
 // Internal force: one lane per node; sums the element pairs fe[(a*n_e+e)*2 + i] in incidence order.
 __global__ void __launch_bounds__(kBlock)
 force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t* __restrict__ ilist,

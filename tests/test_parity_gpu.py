@@ -229,6 +229,27 @@ def test_p1_fused_step_is_bitwise_the_two_kernel_route(fep, monkeypatch, name):
     assert np.array_equal(a[0]['K'].data, a[2]['K'].data)
 
 
+@pytest.mark.parametrize('t,n', [('P2', 40), ('Q2', 30), ('Q1', 50)])
+def test_reduce_kernel_forms_are_bitwise_equal(fep, monkeypatch, t, n):
+    """COO route: the reduce kernel with packed block descriptors and four contribution addresses per load against the
+    round-1 form (segptr / meta / one address per load, 2 to 8 gathers in flight): same adds in the same order."""
+    mesh = fep.square_mesh(n, t, 10)
+    x, y = mesh['coordinates']
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    res = []
+    for env in ({}, {'FEP_CSR_UNPACKED': '1', 'FEP_CSR_GATHERS': '2'}, {'FEP_CSR_UNPACKED': '1', 'FEP_CSR_GATHERS': '8'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
+        ctx.set_materials(*[v[0] for v in dp_materials(1)])
+        r = ctx.step(U, np.zeros((4, ctx.n_int)), want=('K', 'F'))
+        res.append((r['K'].data.copy(), r['F'].copy(), r['n_smooth'], r['n_apex']))
+        ctx.close()
+    assert res[0][2] > 0 and res[0][3] > 0
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and res[0][2:] == other[2:]
+
+
 def test_p1_assembly_from_staged_nodes_is_bitwise_the_record_form(fep, monkeypatch):
     """FEP_P1_ASM=nodes: the assembly kernel takes its geometry from the tile's LDS-staged nodes instead of the 48-byte
     records; same K, F bit for bit (full-output step, accepting step, assemble_tangent)."""
