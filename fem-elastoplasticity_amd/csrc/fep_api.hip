@@ -589,6 +589,14 @@ extern "C" int fep_ctx_set_materials_host(fep_ctx* c, const double* shear_h, con
     HIP_TRY(hipMemcpy(c->eta, eta_h, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->c, c_h, nb, hipMemcpyHostToDevice));
     c->have_materials = true;
+    // the two-kernel node routes pass ds / s from the point kernel to the assembly kernel through HBM: when the caller
+    // wants K / F without them the scratch must exist before the first fep_step_dev (which may run inside a stream
+    // capture, where allocating is illegal).  P1 contexts with the one-kernel step only need it for accepting calls that
+    // also ask for K / F without ds / s (allocated on first use, outside any capture, by those rare callers).
+    if ((c->p1_node && !c->p1_fused) || c->gn) {
+        if (!c->ds_int) FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int));
+        if (!c->s_int) FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int));
+    }
     // every parameter constant over the mesh (the reference's demos): the kernels skip the four arrays
     bool uni = std::getenv("FEP_NO_UNIFORM") == nullptr;
     for (int64_t k = 1; uni && k < c->n_int; ++k)

@@ -154,9 +154,10 @@ int fep_ctx_device_ptr(const fep_ctx* ctx, int which, void** ptr_d);
  *   k_data     out (nnz)     f_out  out (n_dof)
  *   counts     out [2] {n_smooth, n_apex} or NULL
  *
- * No allocation and no synchronisation happens in fep_step_dev once every output the caller wants has been
- * passed at least once (internal ds / s scratch is allocated on first use when k_data / f_out are requested
- * without ds / s), so the call can be captured into a hipGraph.  Results are bitwise reproducible run to run
+ * fep_step_dev neither allocates nor synchronises, so the call can be captured into a hipGraph.  (One exception: a P1
+ * context asked for k_data / f_out on an ACCEPTING call without ds / s allocates its ds / s scratch on the first such
+ * call; make that call once outside a capture.  P1 non-accepting calls without point outputs run as one kernel and need
+ * no scratch; the other routes get theirs in fep_ctx_set_materials_host.)  Results are bitwise reproducible run to run
  * (fixed summation order, no floating-point atomics).
  */
 int fep_step_dev(fep_ctx* ctx, void* stream, const double* u_d, const double* e0_h,

@@ -300,7 +300,7 @@ def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
 
 @pytest.fixture(params=['node', 'coo'])
 def gen_route(request, monkeypatch):
-    """P2 / Q1 / Q2 have two routes: node route (default) and the COO route (also what P4 uses)."""
+    """P2 / Q1 / Q2 have two routes: the COO route (default, also what P4 uses) and the opt-in node route."""
     monkeypatch.setenv('FEP_GEN_PATH', request.param)
     return request.param
 
