@@ -1,0 +1,56 @@
+"""bench.py's contract with the driver, at a small size: `python bench.py [--gpus N]` exits 0 and prints ONE JSON line
+with the fields the task statement names (+ roofline, cpu_baseline at N = 1); `--gpus 2` invoked as a plain command starts
+its own two ranks (here both on cuda:0 over gloo: FEP_BENCH_SINGLE_DEVICE) in weak and strong mode."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline'}
+
+
+def _run(args, env=None):
+    e = dict(os.environ, **(env or {}))
+    e.pop('WORLD_SIZE', None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=e, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    j = _run(['--cells', '96', '--steps', '3', '--warmup', '1'])
+    assert KEYS <= set(j) and 'cpu_baseline' in j and 'kf_only' in j
+    assert j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 1 and j['dtype'] == 'f64' and j['vs_baseline'] is None
+    assert j['unit'] == 'updates/s' and j['higher_is_better'] is True and j['data'] == 'synthetic'
+    n = 2 * 96 * 96
+    assert j['config']['elements_per_gpu'] == n and 'BASELINE configs[3]' not in j['config']['workload']   # only at 708 cells
+    assert abs(j['value'] - n * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']
+    r = j['roofline']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert r['traffic'] is None and abs(r['algorithmic_bytes_per_launch'] - 537.0 * n) < 1e-6     # traffic only for the profiled size
+    assert j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['cores'] == 1 and j['cpu_baseline']['value'] > 0
+    assert 0 < j['config']['smooth_points'] and 0 < j['config']['apex_points']
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_two_ranks_started_by_bench_itself(scaling):
+    j = _run(['--gpus', '2', '--backend', 'gloo', '--cells', '96', '--steps', '3', '--warmup', '1', '--scaling', scaling],
+             env={'FEP_BENCH_SINGLE_DEVICE': '1'})
+    assert KEYS <= set(j) and j['n_gpus'] == 2 and j['scaling'] == scaling and 'cpu_baseline' not in j
+    n = 2 * 96 * 96
+    assert j['config']['elements_total'] == (n if scaling == 'strong' else 2 * n)
+    assert len(j['per_rank']) == 2 and j['exchange_ms'] > 0
+    assert ('strong' in j) == (scaling == 'weak')
+    if scaling == 'weak':
+        assert j['strong']['elements_total'] == n and sum(r['elements'] for r in j['strong']['per_rank']) == n
+    assert abs(j['value'] - j['config']['elements_total'] * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']
