@@ -14,7 +14,11 @@ The linear solve (the reference's dense `np.linalg.solve` on a (2 n_n)^2 boolean
                           the plastic strain and the stopping norms then never leave the device, or
   linear_solver='amg'     the same with the smoothed-aggregation multigrid preconditioner built once from K_elast.
 `pcg_forcing` (e.g. 1e-2) makes the Newton iteration inexact: the linear tolerance follows the previous iterate's
-stopping quantity instead of being 1e-11 throughout; the converged states are the same to the Newton tolerance.
+stopping quantity instead of being 1e-11 throughout (never looser than `pcg_forcing_cap`); `pcg_inexact_rtol` (e.g. 1e-2)
+asks every linear solve for that relative residual only — Newton then converges linearly with about that factor instead
+of quadratically, which on plastic tangents (hundreds of CG iterations per digit) is much the cheaper trade: BASELINE
+configs[3] end to end 42 s -> 19 s with the same load history (tools/newton_bench.py --inexact 1e-2).  The converged
+states are the same to the Newton tolerance either way.
 `transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is re-stated
 with `np.bincount` on the host and as `fep_transform_dev` on the device.
 """
@@ -85,13 +89,14 @@ class _DeviceOps:
     `KrylovSolver.pcg` solves on them.  A linear solve that breaks down or runs out of iterations yields NaNs,
     which the drivers treat like the reference treats a NaN criterion (DP:1076): the load step is halved."""
 
-    def __init__(self, ctx, qf, rtol=1e-11, max_iter=200000, forcing=None):
+    def __init__(self, ctx, qf, rtol=1e-11, max_iter=200000, forcing=None, forcing_cap=1e-4, inexact_rtol=None):
         import torch
         from .solver import KrylovSolver
         self.torch, self.ctx, self.qf = torch, ctx, qf
         self.dev = torch.device('cuda', ctx.device)
         self.solver = KrylovSolver(ctx, qf)
-        self.rtol, self.max_iter, self.forcing = rtol, max_iter, forcing
+        self.rtol, self.max_iter, self.forcing, self.forcing_cap = rtol, max_iter, forcing, forcing_cap
+        self.inexact_rtol = inexact_rtol
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.kd = torch.empty(ctx.nnz, **f64)
         self.F = torch.empty(ctx.n_dof, **f64)
@@ -136,10 +141,12 @@ class _DeviceOps:
     def solve(self, K, rhs, criterion=None):
         # inexact Newton: while the iterate is far from converged the correction need not be solved to 11 digits.
         # `criterion` is the stopping quantity of the previous Newton iterate (DP:1075); the linear residual is asked
-        # to be `forcing` times smaller than it, never looser than 1e-4 nor tighter than `rtol`.
+        # to be `forcing` times smaller than it, never looser than `forcing_cap` (1e-4) nor tighter than `rtol`.
         rtol = self.rtol
-        if self.forcing and criterion is not None and np.isfinite(criterion):
-            rtol = min(1e-4, max(self.rtol, self.forcing * criterion))
+        if self.inexact_rtol and criterion is not None:        # (the elastic solves before the loop pass no criterion)
+            rtol = max(self.rtol, self.inexact_rtol)
+        elif self.forcing and criterion is not None and np.isfinite(criterion):
+            rtol = min(self.forcing_cap, max(self.rtol, self.forcing * criterion))
         x = self.solver.pcg(K, rhs, rtol=rtol, max_iter=self.max_iter)
         self.pcg_iters.append(self.solver.last['iters'])
         if self.solver.last['state'] != 1:
@@ -167,19 +174,19 @@ class _DeviceOps:
         self.solver.close()
 
 
-def _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing=None):
+def _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing=None, pcg_forcing_cap=1e-4, pcg_inexact_rtol=None):
     if linear_solver == 'direct':
         return _HostOps(ctx, qf)
     if linear_solver in ('pcg', 'amg'):
         if not isinstance(ctx, MeshContext):
             raise ValueError(f"linear_solver='{linear_solver}' needs the GPU MeshContext")
-        return _DeviceOps(ctx, qf, rtol=pcg_rtol, forcing=pcg_forcing)
+        return _DeviceOps(ctx, qf, rtol=pcg_rtol, forcing=pcg_forcing, forcing_cap=pcg_forcing_cap, inexact_rtol=pcg_inexact_rtol)
     raise ValueError("linear_solver must be 'direct', 'pcg' or 'amg'")
 
 
 def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, max_steps=None, zeta_max=1.0,
                         device=None, log=None, context_factory=None, linear_solver='direct', pcg_rtol=1e-11,
-                        keep_U=True, pcg_forcing=None):
+                        keep_U=True, pcg_forcing=None, pcg_forcing_cap=1e-4, pcg_inexact_rtol=None):
     """Strip-footing benchmark of Plasticity2D_DP (DP:901-1131).  `level` as in the reference
     (N = size_xy * 2**level cells per side) or `n_cells` directly.  Returns a dict with the load history
     ('zeta', 'pressure'), the accepted displacements 'U' (list of (2,n_n)), final 'Ep', counters.
@@ -199,7 +206,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     ctx = (context_factory or (lambda *a: MeshContext(*a, device=device)))(elem, coord, d1, d2, wf)
     ctx.set_materials(shear0, bulk0, eta0, c_0)
     qf = Q.flatten(order='F')
-    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing)
+    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing, pcg_forcing_cap, pcg_inexact_rtol)
     K_elast = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                        # DP:977
     if linear_solver == 'amg':
         ops.setup_amg(K_elast, coord)
@@ -272,7 +279,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
 
 
 def solve_tsx_tunnel(coords=None, elem=None, element_type='P1', n_load_steps=17, monitor=(0, 40), device=None, log=None,
-                     linear_solver='direct', pcg_rtol=1e-11, pcg_forcing=None, mesh_dir=None):
+                     linear_solver='direct', pcg_rtol=1e-11, pcg_forcing=None, mesh_dir=None, pcg_inexact_rtol=None):
     """TSX tunnel excavation (TSX:1637-1832) on a given mesh (`coords` (2,n_n), `elem` (n_p,n_e) 0-based), or — as the
     reference does at TSX:1687-1690 — on the mesh read from `mesh_dir`/coord.csv, elem.csv with the midpoints of
     `element_type` added.  Returns the history of the monitored displacement, plastic-point counts and accepted
@@ -304,7 +311,7 @@ def solve_tsx_tunnel(coords=None, elem=None, element_type='P1', n_load_steps=17,
     n_int = ctx.n_int
     assert n_int == elem.shape[1] * ELEMENT_SHAPE[t][1]
     ctx.set_materials(shear0, bulk0, eta0, c_0)
-    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing)
+    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing, pcg_inexact_rtol=pcg_inexact_rtol)
     K = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                              # TSX:1722
     if linear_solver == 'amg':
         ops.setup_amg(K, coords)

@@ -154,6 +154,17 @@ def test_inexact_newton_reaches_the_same_states_with_fewer_cg_iterations(fep):
     assert len(h['zeta']) == 16 and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
     for k in range(16):
         assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-9, k
+    # every linear solve to two digits only: Newton converges linearly, the accepted states are the reference's
+    d = fep.solve_strip_footing('P1', n_cells=48, max_steps=6, linear_solver='amg', pcg_inexact_rtol=1e-2)
+    assert a['zeta'] == d['zeta'] and a['counts'] == d['counts']
+    for k in range(6):
+        assert relerr(a['U'][k], d['U'][k]) <= 1e-9, k
+    assert sum(d['pcg_iters']) < 0.6 * sum(b['pcg_iters'])
+    h = fep.solve_strip_footing('P1', level=1, linear_solver='amg', pcg_inexact_rtol=1e-2)
+    assert len(h['zeta']) == 16 and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
+    for k in range(16):
+        assert relerr(h['U'][k], g['U_accepted'][k]) <= 1e-9, k
+    assert np.abs(np.array(h['pressure'][:15]) - g['pressure'][1:16]).max() <= 1e-8 * np.abs(g['pressure']).max()
 
 
 def test_solver_rejects_foreign_patterns(fep):

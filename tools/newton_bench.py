@@ -18,12 +18,14 @@ ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--element', default='P1')
 ap.add_argument('--rtol', type=float, default=1e-10)
 ap.add_argument('--forcing', type=float, default=0.0, help='inexact Newton: linear rtol = forcing * previous Newton criterion (0 = fixed rtol)')
+ap.add_argument('--inexact', type=float, default=0.0, help='constant relative tolerance of every linear solve inside the Newton loop (0 = off)')
+ap.add_argument('--cap', type=float, default=1e-4, help='loosest linear tolerance the forcing term may ask for')
 ap.add_argument('--solver', default='amg', help='pcg (block-Jacobi CG) | amg (multigrid-preconditioned CG) | direct')
 a = ap.parse_args()
 
 lines = []
 t0 = time.perf_counter()
-h = fep.solve_strip_footing(a.element, n_cells=a.n, max_steps=a.steps, linear_solver=a.solver, pcg_rtol=a.rtol, pcg_forcing=a.forcing or None,
+h = fep.solve_strip_footing(a.element, n_cells=a.n, max_steps=a.steps, linear_solver=a.solver, pcg_rtol=a.rtol, pcg_forcing=a.forcing or None, pcg_forcing_cap=a.cap, pcg_inexact_rtol=a.inexact or None,
                             keep_U=False, log=lambda s: (lines.append(s), print(f'[{time.perf_counter() - t0:8.2f}s] {s}', flush=True)))
 t = time.perf_counter() - t0
 it = h['pcg_iters'] or []
