@@ -16,3 +16,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -- "$@" > $out/write.log
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY -d $out/sq -- "$@" > $out/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $out/sq2 -- "$@" > $out/sq2.log 2>&1
 python3 tools/summarize_counters.py $tag $out $extra
+# the summaries land in profiles/ of THIS checkout; on a gpurun box only gpurun_out/ travels back: leave copies there
+cp profiles/${tag}_kernel_stats.csv profiles/${tag}_counters.csv $out/ 2>/dev/null || true
