@@ -255,7 +255,9 @@ int fep_aggregate_host(int64_t n, const int32_t* indptr, const int32_t* indices,
  * brackets each of its kernels with HIP events on the launch stream (the kernels run in their real
  * position inside the step, not replayed back to back).  _end synchronises the stream and returns
  * the average milliseconds per launch.  P1 (node route): ms_out[0] p1_point_kernel (strain + return map),
- * ms_out[1] p1_node_lds_kernel (tangent CSR values + force), ms_out[2] 0.  Other element types / COO route:
+ * ms_out[1] p1_node_lds_kernel (tangent CSR values + force), ms_out[2] 0; a P1 step that runs as ONE kernel (no point
+ * output wanted, not accepting): ms_out[0] = the gap between two event marks (~0.005), ms_out[1] p1_fused_kernel
+ * (+ the one-workgroup counter sum).  Other element types / COO route:
  * ms_out[0] element_kernel (strain + return map + K_e, f_e), ms_out[1] csr_reduce_kernel, ms_out[2]
  * force_reduce_kernel.  *n_steps = steps averaged. */
 int fep_ctx_profile_begin(fep_ctx* ctx);
