@@ -100,3 +100,25 @@ def test_two_row_tiles_stage_fewer_elements_on_a_row_numbered_mesh(fep, binaries
     _dump(path, t['elem'], t['coord'].shape[1])
     out = subprocess.run([binaries['asan'], path, '2'], stdout=subprocess.PIPE, text=True).stdout
     assert [l for l in out.splitlines() if l.startswith('p1 plan [default]')][0].count(' segs 1 ') == 1
+
+
+def test_random_meshes_through_the_plan_validator(fep, binaries, tmp_path):
+    """Fuzz: Delaunay meshes of random sizes, random node / element numberings, random dropped elements (which leaves
+    nodes of no element and irregular degrees), every segment count — each plan must validate, under ASan / UBSan."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(20261004)
+    for trial in range(6):
+        n_pts = int(rng.integers(30, 1500))
+        pts = rng.random((n_pts, 2)) * [10.0, rng.uniform(1.0, 10.0)]
+        tri = Delaunay(pts).simplices.T
+        if trial % 2:
+            perm = rng.permutation(n_pts)
+            tri = perm[tri]
+            tri = tri[:, rng.permutation(tri.shape[1])]
+        if trial % 3 == 0:
+            tri = tri[:, rng.random(tri.shape[1]) > 0.3]
+        path = str(tmp_path / f'fuzz{trial}.bin')
+        _dump(path, tri, n_pts)
+        for segs in ('1', '2', '4'):
+            res = subprocess.run([binaries['asan'], path, segs], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+            assert res.returncode == 0 and 'result ok' in res.stdout, (trial, segs, res.stdout[-2000:])
