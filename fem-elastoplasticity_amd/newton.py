@@ -17,7 +17,7 @@ The linear solve (the reference's dense `np.linalg.solve` on a (2 n_n)^2 boolean
 stopping quantity instead of being 1e-11 throughout (never looser than `pcg_forcing_cap`); `pcg_inexact_rtol` (e.g. 1e-2)
 asks every linear solve for that relative residual only — Newton then converges linearly with about that factor instead
 of quadratically, which on plastic tangents (hundreds of CG iterations per digit) is much the cheaper trade: BASELINE
-configs[3] end to end 42 s -> 19 s with the same load history (tools/newton_bench.py --inexact 1e-2).  The converged
+configs[3] end to end 42 s -> 15 s with the same load history (tools/newton_bench.py --inexact 1e-2).  The converged
 states are the same to the Newton tolerance either way.
 `transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is re-stated
 with `np.bincount` on the host and as `fep_transform_dev` on the device.

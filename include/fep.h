@@ -227,8 +227,9 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
 /* Multigrid preconditioner for the same solve (smoothed aggregation).  The hierarchy is built on the host (solver.py:
  * aggregates from fep_aggregate_host, rigid-body-mode prolongators, Galerkin products with SciPy) from a reference
  * matrix on the context's pattern — normally K_elast — and pushed level by level; the solver applies it as a V(2,2)
- * cycle with damped block-Jacobi smoothing in which level 0 is always the CURRENT tangent (k_data_d of the call) and
- * the coarse operators stay those of the reference matrix.
+ * cycle in which level 0 is always the CURRENT tangent (k_data_d of the call) and the coarse operators stay those of the
+ * reference matrix.  Smoother: degree-2 Chebyshev in D^-1 A on [lmax/20, lmax], lmax = 1.2 x the value the hierarchy's
+ * omega encodes (omega = 4 / (3 * 1.05 * rho)); FEP_AMG_SMOOTHER=jacobi selects two damped block-Jacobi sweeps instead.
  *
  *   fep_solver_amg_push_level   transfer level k -> k+1 (k = number of levels pushed so far; level 0 = the mesh DOFs):
  *       P (n_fine x n_coarse) and R = P^T (n_coarse x n_fine) in CSR; A = operator of level k+1 (n_coarse^2, CSR) or,
