@@ -23,7 +23,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int NODES_PER_WAVE = 4;           // 8 lanes per DOF row, 8 rows per wave and pass
+constexpr int NODES_PER_WAVE = 8;           // 8 lanes per NODE (both of its DOF rows), 8 nodes per wave and pass
 constexpr int SPMV_PASSES = 4;              // passes per wave (independent, for loads in flight)
 constexpr int NODES_PER_BLOCK = (TPB / 64) * NODES_PER_WAVE * SPMV_PASSES;
 
@@ -136,39 +136,40 @@ spmv_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32_t* __rest
             double* __restrict__ y, const double* __restrict__ dotv, double* __restrict__ part_d) {
     __shared__ double sh[TPB / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & 7, grp = lane >> 3;            // 8 lanes per DOF row
-    const int comp = grp & 1;
-    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + (grp >> 1);
+    const int sub = lane & 7, grp = lane >> 3;            // 8 lanes per node: lane `sub` takes the node's blocks sub, sub+8, ...
+    // both DOF rows of a node share their column list and their x values: one lane forms both partial sums of its
+    // blocks (k row 0, k row 1, neighbour id and x fetched once) instead of two lane groups fetching ids and x twice
+    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + grp;
     double dot = 0.0;
-    double acc[SPMV_PASSES];
-    int64_t nn[SPMV_PASSES];
+    double acc0[SPMV_PASSES], acc1[SPMV_PASSES];
 #pragma unroll
     for (int ps = 0; ps < SPMV_PASSES; ++ps) {
         const int64_t n = node0 + ps * NODES_PER_WAVE;
-        nn[ps] = n;
-        acc[ps] = 0.0;
+        acc0[ps] = 0.0; acc1[ps] = 0.0;
         if (n < n_n) {
             const int b0 = nptr[n], deg = nptr[n + 1] - b0;
-            const double2* row = K2 + 2 * (int64_t)b0 + (int64_t)comp * deg;
+            const double2* row0 = K2 + 2 * (int64_t)b0;
+            const double2* row1 = row0 + deg;
             for (int t = sub; t < deg; t += 8) {
-                const double2 k = row[t];
+                const double2 k0 = row0[t], k1 = row1[t];
                 const double2 xv = x[ncol[b0 + t]];
-                acc[ps] += k.x * xv.x + k.y * xv.y;
+                acc0[ps] += k0.x * xv.x + k0.y * xv.y;
+                acc1[ps] += k1.x * xv.x + k1.y * xv.y;
             }
         }
     }
 #pragma unroll
     for (int ps = 0; ps < SPMV_PASSES; ++ps) {
-        double a = acc[ps];
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        a += __shfl_xor(a, 4, 64);
-        const int64_t n = nn[ps];
+        double a0 = acc0[ps], a1 = acc1[ps];
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+        a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
+        a0 += __shfl_xor(a0, 4, 64); a1 += __shfl_xor(a1, 4, 64);
+        const int64_t n = node0 + ps * NODES_PER_WAVE;
         if (sub == 0 && n < n_n) {
-            const int64_t dof = 2 * n + comp;
-            if (MASKED && !free_dof[dof]) a = 0.0;
-            y[dof] = a;
-            if (dotv) dot += a * dotv[dof];
+            if (MASKED && !free_dof[2 * n]) a0 = 0.0;
+            if (MASKED && !free_dof[2 * n + 1]) a1 = 0.0;
+            reinterpret_cast<double2*>(y)[n] = make_double2(a0, a1);
+            if (dotv) { const double2 dv = reinterpret_cast<const double2*>(dotv)[n]; dot += a0 * dv.x + a1 * dv.y; }
         }
     }
     if (part_d) {
@@ -228,50 +229,52 @@ block_residual_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32
                       double omega, double* __restrict__ out,
                       double ca = 1.0, double cprev = 0.0, const double2* __restrict__ xprev = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & 7, grp = lane >> 3, comp = grp & 1;
-    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + (grp >> 1);
-    double acc[SPMV_PASSES];
+    const int sub = lane & 7, grp = lane >> 3;            // 8 lanes per node, both DOF rows per lane (see spmv_kernel)
+    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + grp;
+    double acc0[SPMV_PASSES], acc1[SPMV_PASSES];
 #pragma unroll
     for (int ps = 0; ps < SPMV_PASSES; ++ps) {
         const int64_t n = node0 + ps * NODES_PER_WAVE;
-        acc[ps] = 0.0;
+        acc0[ps] = 0.0; acc1[ps] = 0.0;
         if (n < n_n) {
             const int b0 = nptr[n], deg = nptr[n + 1] - b0;
-            const double2* row = K2 + 2 * (int64_t)b0 + (int64_t)comp * deg;
+            const double2* row0 = K2 + 2 * (int64_t)b0;
+            const double2* row1 = row0 + deg;
             for (int t = sub; t < deg; t += 8) {
-                const double2 k = row[t];
+                const double2 k0 = row0[t], k1 = row1[t];
                 const double2 xv = x[ncol[b0 + t]];
-                acc[ps] += k.x * xv.x + k.y * xv.y;
+                acc0[ps] += k0.x * xv.x + k0.y * xv.y;
+                acc1[ps] += k1.x * xv.x + k1.y * xv.y;
             }
         }
     }
 #pragma unroll
     for (int ps = 0; ps < SPMV_PASSES; ++ps) {
-        double a = acc[ps];
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        a += __shfl_xor(a, 4, 64);
+        double a0 = acc0[ps], a1 = acc1[ps];
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+        a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
+        a0 += __shfl_xor(a0, 4, 64); a1 += __shfl_xor(a1, 4, 64);
         const int64_t n = node0 + ps * NODES_PER_WAVE;
-        const bool live = n < n_n;
-        const int64_t dof = 2 * n + comp;
-        double r = 0.0;
-        if (live && sub == 0 && free_dof[dof]) r = b[dof] - a;
+        if (sub != 0 || n >= n_n) continue;
+        const bool f0 = free_dof[2 * n] != 0, f1 = free_dof[2 * n + 1] != 0;
+        const double2 bv = reinterpret_cast<const double2*>(b)[n];
+        const double r0 = f0 ? bv.x - a0 : 0.0, r1 = f1 ? bv.y - a1 : 0.0;
         if (SMOOTH) {
-            const double other = __shfl_xor(r, 8, 64);              // the node's other component
-            if (live && sub == 0) {
-                const double r0 = comp == 0 ? r : other, r1 = comp == 0 ? other : r;
-                const double m0 = minv[3 * n], m1 = minv[3 * n + 1], m2 = minv[3 * n + 2];
-                const double d = comp == 0 ? m0 * r0 + m1 * r1 : m1 * r0 + m2 * r1;
-                const double xo = comp == 0 ? x[n].x : x[n].y;
-                if (SMOOTH == 2) {
-                    const double xp = xprev ? (comp == 0 ? xprev[n].x : xprev[n].y) : 0.0;
-                    out[dof] = free_dof[dof] ? ca * xo + cprev * xp + omega * d : 0.0;
-                } else {
-                    out[dof] = free_dof[dof] ? xo + omega * d : 0.0;
-                }
+            const double m0 = minv[3 * n], m1 = minv[3 * n + 1], m2 = minv[3 * n + 2];
+            const double d0 = m0 * r0 + m1 * r1, d1 = m1 * r0 + m2 * r1;
+            const double2 xo = x[n];
+            double o0, o1;
+            if (SMOOTH == 2) {
+                const double2 xp = xprev ? xprev[n] : make_double2(0.0, 0.0);
+                o0 = ca * xo.x + cprev * xp.x + omega * d0;
+                o1 = ca * xo.y + cprev * xp.y + omega * d1;
+            } else {
+                o0 = xo.x + omega * d0;
+                o1 = xo.y + omega * d1;
             }
-        } else if (live && sub == 0) {
-            out[dof] = r;
+            reinterpret_cast<double2*>(out)[n] = make_double2(f0 ? o0 : 0.0, f1 ? o1 : 0.0);
+        } else {
+            reinterpret_cast<double2*>(out)[n] = make_double2(r0, r1);
         }
     }
 }
