@@ -100,7 +100,7 @@ def _stream(torch, device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=200, max_levels=8):
+def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8):
     """Smoothed-aggregation hierarchy of Q K Q + (I - Q) (host, SciPy).  Returns one dict per transfer k -> k+1:
     'P' (n_k x n_{k+1}), 'R' = P^T, 'A' = operator of level k+1 (its dense INVERSE in CSR form when 'last'),
     'D' = inverse of A's 3x3 block diagonal (None when 'last'), 'omega' = Jacobi damping on level k, 'size' =
@@ -190,7 +190,7 @@ class KrylovSolver:
             raise ValueError(f'expected {n} contiguous float64 values')
         return v
 
-    def setup_amg(self, K_ref, coordinates, coarse_nodes=200, max_levels=8):
+    def setup_amg(self, K_ref, coordinates, coarse_nodes=400, max_levels=8):
         """Builds the multigrid hierarchy from `K_ref` (csr_matrix on the pattern, or its data array; host) and the
         node coordinates (2, n_n), and loads it onto the device.  Returns [(DOFs, nnz)] per level."""
         if not hasattr(self, '_pattern'):

@@ -13,6 +13,7 @@ import bench  # noqa: E402
 import torch  # noqa: E402
 
 fep = importlib.import_module('fem-elastoplasticity_amd')
+coarse = int(os.environ.get('AMG_COARSE_NODES', '400'))
 for N in [int(a) for a in sys.argv[1:]] or [256]:
     mesh = fep.square_mesh(N, 'P1', 10)
     ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
@@ -21,7 +22,7 @@ for N in [int(a) for a in sys.argv[1:]] or [256]:
     qf = mesh['Q'].flatten(order='F')
     sol = fep.KrylovSolver(ctx, qf)
     t0 = time.perf_counter()
-    levels = sol.setup_amg(K, mesh['coordinates'])
+    levels = sol.setup_amg(K, mesh['coordinates'], coarse_nodes=coarse)
     t_setup = time.perf_counter() - t0
     dev = torch.device('cuda', 0)
     kd = torch.from_numpy(K.data).to(dev)
