@@ -655,23 +655,26 @@ static int launch_counts(fep_ctx* c, hipStream_t st, unsigned long long* counts_
     return FEP_OK;
 }
 
-// COO route, numeric phase: K_e blocks -> CSR values, f_e pairs -> nodal force
+// COO route, numeric phase: K_e blocks -> CSR values, f_e pairs -> nodal force (the force gather rides in the reduce
+// kernel's launch: the workgroups past the last tile take 256 nodes each)
 static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_out,
                          unsigned long long* counts_d = nullptr, bool* counts_done = nullptr) {
     if (counts_done) *counts_done = false;
     FEP_TRY(prof_mark(c, st));
+    bool force_done = false;
     if (k_data) {
+        ForceArgs fa{c->n_n, c->iptr, c->ilist, c->fe, f_out};
+        const unsigned grid = (unsigned)c->n_wg_p1 + (counts_d ? 1u : 0u) + (f_out ? grid_for(c->n_n, kBlock) : 0u);
 #define CSR_REDUCE(G)                                                                                                    \
-    hipLaunchKernelGGL(csr_reduce_kernel<G>, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st,                 \
+    hipLaunchKernelGGL(csr_reduce_kernel<G>, dim3(grid), dim3(kBlock), 0, st,                                            \
                        c->n_wg_p1, c->tstart, c->segptr, c->perm, c->meta, c->Kc, k_data, c->n_count_blocks,             \
-                       c->blk_counts, counts_d)
+                       c->blk_counts, counts_d, fa)
         if (c->pkc)
-            hipLaunchKernelGGL(csr_reduce_pk_kernel, dim3(c->n_wg_p1 + (counts_d ? 1 : 0)), dim3(kBlock), 0, st, c->n_wg_p1,
-                               c->tstart, c->pkc, c->perm, c->Kc, k_data, c->n_count_blocks, c->blk_counts, counts_d);
+            hipLaunchKernelGGL(csr_reduce_pk_kernel, dim3(grid), dim3(kBlock), 0, st, c->n_wg_p1,
+                               c->tstart, c->pkc, c->perm, c->Kc, k_data, c->n_count_blocks, c->blk_counts, counts_d, fa);
         else
         switch (c->csr_gathers) {
             case 2: CSR_REDUCE(2); break;
-            case 4: CSR_REDUCE(4); break;
             case 6: CSR_REDUCE(6); break;
             case 8: CSR_REDUCE(8); break;
             default: CSR_REDUCE(4); break;
@@ -679,9 +682,10 @@ static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_o
 #undef CSR_REDUCE
         HIP_TRY(hipGetLastError());
         if (counts_done) *counts_done = counts_d != nullptr;
+        force_done = f_out != nullptr;
     }
     FEP_TRY(prof_mark(c, st));
-    if (f_out) {
+    if (f_out && !force_done) {
         hipLaunchKernelGGL(force_reduce_kernel, dim3(grid_for(c->n_n, kBlock)), dim3(kBlock), 0, st,
                            c->n_n, c->iptr, c->ilist, c->fe, f_out);
         HIP_TRY(hipGetLastError());

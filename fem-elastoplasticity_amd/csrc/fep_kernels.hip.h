@@ -441,6 +441,29 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 //   meta[blk] = (deg(n) << 16) | (diag << 15) | s
 //   CSR data: row 2n+i starts at 4*nptr[n] + i*2*deg, entry (slot s, comp j) at + 2s + j.
 // ---------------------------------------------------------------------------------------
+// Internal force: one lane per node; sums the element pairs fe[(a*n_e+e)*2 + i] in incidence order.
+__device__ __forceinline__ void force_rows(int64_t n, int64_t n_n, const int32_t* __restrict__ iptr,
+                                           const int32_t* __restrict__ ilist, const double* __restrict__ fe,
+                                           double* __restrict__ F) {
+    if (n >= n_n) return;
+    double f0 = 0.0, f1 = 0.0;
+    for (int32_t t = iptr[n]; t < iptr[n + 1]; ++t) {
+        const double2 v = *reinterpret_cast<const double2*>(fe + (int64_t)ilist[t] * 2);
+        f0 += v.x; f1 += v.y;
+    }
+    *reinterpret_cast<double2*>(F + 2 * n) = make_double2(f0, f1);
+}
+
+__global__ void __launch_bounds__(kBlock)
+force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t* __restrict__ ilist,
+                    const double* __restrict__ fe, double* __restrict__ F) {
+    force_rows((int64_t)blockIdx.x * kBlock + threadIdx.x, n_n, iptr, ilist, fe, F);
+}
+
+// What the reduce kernels take to do the force gather in the SAME launch: the workgroups past the last tile take 256
+// nodes each (F == nullptr: no such workgroups).  One launch and one tail instead of two.
+struct ForceArgs { int64_t n_n; const int32_t* iptr; const int32_t* ilist; const double* fe; double* F; };
+
 // G = gathers in flight per lane: the lane's contributions are fetched G at a time — first their G addresses
 // (independent loads: the segment bounds are known), then the G 32-byte blocks, then summed in list order (the
 // summation order does not depend on G).  The kernel is a chain of dependent gathers (86 % of its wave cycles sit in
@@ -450,7 +473,8 @@ __global__ void __launch_bounds__(kBlock)
 csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t* __restrict__ segptr,
                   const int32_t* __restrict__ perm, const uint32_t* __restrict__ meta,
                   const double* __restrict__ Kc, double* __restrict__ data,
-                  int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
+                  int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out,
+                  ForceArgs fa) {
     // one workgroup = one tile of whole nodes, blocks [tstart[g], tstart[g+1]) (<= kBlock): its 4*nb CSR values
     // are one contiguous range, staged in LDS and written as full consecutive lines (a lane's two 16-byte pieces
     // belong to two different rows; direct stores fill every line in two half passes)
@@ -459,7 +483,7 @@ csr_reduce_kernel(int n_tiles, const int32_t* __restrict__ tstart, const int32_t
     // its serial chain runs under the tiles, not after them)
     const int g = counts_out != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     if (g < 0) { sum_block_counts(n_count_blocks, blk_counts, counts_out); return; }
-    if (g >= n_tiles) return;
+    if (g >= n_tiles) { if (fa.F) force_rows((int64_t)(g - n_tiles) * kBlock + threadIdx.x, fa.n_n, fa.iptr, fa.ilist, fa.fe, fa.F); return; }
     const int64_t sb0 = tstart[g];
     const int nb = tstart[g + 1] - (int)sb0;
     const int64_t sb = sb0 + threadIdx.x;
@@ -506,11 +530,12 @@ struct __attribute__((packed, aligned(4))) PermQuad { int32_t v[4]; };
 __global__ void __launch_bounds__(kBlock)
 csr_reduce_pk_kernel(int n_tiles, const int32_t* __restrict__ tstart, const uint2* __restrict__ pkc,
                      const int32_t* __restrict__ perm, const double* __restrict__ Kc, double* __restrict__ data,
-                     int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
+                     int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out,
+                     ForceArgs fa) {
     __shared__ double2 out2[2 * kBlock];
     const int g = counts_out != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     if (g < 0) { sum_block_counts(n_count_blocks, blk_counts, counts_out); return; }
-    if (g >= n_tiles) return;
+    if (g >= n_tiles) { if (fa.F) force_rows((int64_t)(g - n_tiles) * kBlock + threadIdx.x, fa.n_n, fa.iptr, fa.ilist, fa.fe, fa.F); return; }
     const int64_t sb0 = tstart[g];
     const int nb = tstart[g + 1] - (int)sb0;
     if ((int)threadIdx.x < nb) {
@@ -545,19 +570,7 @@ csr_reduce_pk_kernel(int n_tiles, const int32_t* __restrict__ tstart, const uint
     for (int i = threadIdx.x; i < 2 * nb; i += kBlock) dst[i] = out2[i];
 }
 
-// Internal force: one lane per node; sums the element pairs fe[(a*n_e+e)*2 + i] in incidence order.
-__global__ void __launch_bounds__(kBlock)
-force_reduce_kernel(int64_t n_n, const int32_t* __restrict__ iptr, const int32_t* __restrict__ ilist,
-                    const double* __restrict__ fe, double* __restrict__ F) {
-    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (n >= n_n) return;
-    double f0 = 0.0, f1 = 0.0;
-    for (int32_t t = iptr[n]; t < iptr[n + 1]; ++t) {
-        const double2 v = *reinterpret_cast<const double2*>(fe + (int64_t)ilist[t] * 2);
-        f0 += v.x; f1 += v.y;
-    }
-    *reinterpret_cast<double2*>(F + 2 * n) = make_double2(f0, f1);
-}
+
 
 // transform (DP:760-816): value at a node = weighted mean of the values at the integration points of its
 // elements, weights = quadrature weight * |det J|.  One thread per node over the incidence lists.
