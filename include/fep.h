@@ -196,7 +196,7 @@ int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d,
 /* ---- callers of the hot path ----------------------------------------------------------------
  * transform (DP:760-816): integration-point values (n_int) -> nodal values (n_n), mean over the points of the
  * adjacent elements weighted with quadrature weight * |det J| (the footing pressure that steers the load step,
- * DP:1105). */
+ * DP:1105).  A node that belongs to no element gets 0/0 = NaN, as the reference's F1 / F2 (DP:812) gives. */
 int fep_transform_dev(fep_ctx* ctx, void* stream, const double* q_int_d, double* q_node_d);
 int fep_transform_host(fep_ctx* ctx, const double* q_int_h, double* q_node_h);
 

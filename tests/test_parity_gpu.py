@@ -295,6 +295,9 @@ def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
     assert r['K'].shape == (2 * (n_n + 2), 2 * (n_n + 2))
     K2, F2 = ctx.assemble(r['ds'], r['s'])
     assert np.array_equal(F2, r['F'])
+    # transform: the weighted mean over no element is 0/0 = NaN, as the reference's F1 / F2 (DP:812); finite elsewhere
+    qn = ctx.transform(r['s'][1])
+    assert np.isnan(qn[50]) and np.isnan(qn[-1]) and np.isfinite(np.delete(qn, [50, qn.size - 1])).all()
     ctx.close()
 
 
