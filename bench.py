@@ -147,7 +147,7 @@ class Shard:
         self.ctx.step_dev(stream, self.U.data_ptr(), ep=self.Ep.data_ptr(), accept=False,
                           s=self.S.data_ptr() if full else 0, ds=self.DS.data_ptr() if full else 0,
                           ind_p=self.indp.data_ptr() if full else 0, k_data=self.Kd.data_ptr(),
-                          f_out=self.Fb[i].data_ptr(), counts=self.counts.data_ptr())
+                          f_out=self.Fb[i].data_ptr(), counts=self.counts.data_ptr() if full else 0)   # a Newton iterate logs no counts
 
 
 def run(args):
@@ -271,7 +271,7 @@ def run(args):
         kms_kf, _ = per_kernel(shard, step_kf, args.steps)
         kf = {'ms_per_step': dt_kf / args.steps * 1e3, 'updates_per_s': n_int * args.steps / dt_kf,
               'kernels_ms': {'point': kms_kf['element'], 'assembly': kms_kf['csr'], 'force': kms_kf['force']},
-              'note': 'fep_step_dev with s = ds = ind_p = NULL (newton.py asks for K and F only)'}
+              'note': 'fep_step_dev with s = ds = ind_p = counts = NULL (newton.py asks for K and F only)'}
 
     # strong-scaling companion of a weak run (N > 1): ONE N x N square split over the ranks
     strong_line = None

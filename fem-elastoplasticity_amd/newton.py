@@ -125,7 +125,7 @@ class _DeviceOps:
                           e0=e0, s=self.s.data_ptr() if 's' in want else 0,
                           ind_p=self.ind.data_ptr() if 'ind_p' in want else 0,
                           k_data=0 if kd is None else kd.data_ptr(), f_out=self.F.data_ptr() if 'F' in want else 0,
-                          counts=self.counts.data_ptr())
+                          counts=self.counts.data_ptr() if ('s' in want or 'ind_p' in want) else 0)   # logged on accepting calls only
         out = {'K': kd, 'F': self.F, 's': self.s, 'ind_p': self.ind}
         out = {k: v for k, v in out.items() if k in want}
         if 's' in want or 'ind_p' in want:                     # accepting calls: the counters are logged
