@@ -724,9 +724,8 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
                            k_data, f_out, n_wg, (unsigned long long*)nullptr, k_data ? ds : (const double*)nullptr,      \
                            f_out ? s : (const double*)nullptr, c->n_count_blocks, c->blk_counts, counts_d);              \
     } while (0)
-            const bool e1 = c->lds_L <= 256, n1 = c->lds_NL <= 256;
-            if (c->p1_fused_rng) { if (e1 && n1) ASM4(true, 1, 1); else if (e1) ASM4(true, 1, 2); else if (n1) ASM4(true, 2, 1); else ASM4(true, 2, 2); }
-            else { if (e1 && n1) ASM4(false, 1, 1); else if (e1) ASM4(false, 1, 2); else if (n1) ASM4(false, 2, 1); else ASM4(false, 2, 2); }
+            if (c->lds_L > 256 || c->lds_NL > 256) return FEP_ESTATE;
+            if (c->p1_fused_rng) ASM4(true, 1, 1); else ASM4(false, 1, 1);
 #undef ASM4
             if (counts_done) *counts_done = counts_d != nullptr;
         } else if (c->p1_lds) {
@@ -757,9 +756,8 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
 #define NODE_LDS2(TPB, RNG, EPT) do { if (c->p1_pk) NODE_LDS3(TPB, RNG, EPT, true); else NODE_LDS3(TPB, RNG, EPT, false); } while (0)
 #define NODE_LDS(TPB)                                                                                                    \
     do {                                                                                                                 \
-        const bool one = c->lds_L <= TPB;                                                                                \
-        if (c->p1_rng) { if (one) NODE_LDS2(TPB, true, 1); else NODE_LDS2(TPB, true, 2); }                               \
-        else { if (one) NODE_LDS2(TPB, false, 1); else NODE_LDS2(TPB, false, 2); }                                       \
+        if (c->lds_L > TPB) return FEP_ESTATE;          /* one staged element per lane (fep_host.h) */                  \
+        if (c->p1_rng) NODE_LDS2(TPB, true, 1); else NODE_LDS2(TPB, false, 1);                                           \
     } while (0)
             NODE_LDS(256);                 // tiles of 128 / 512 blocks were measured slower (profiles/r01_ablation.md)
 #undef NODE_LDS
@@ -844,11 +842,8 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
                            (const double*)nullptr, (const double*)nullptr, 0, (const uint2*)nullptr,                     \
                            (unsigned long long*)nullptr);                                                                \
     } while (0)
-#define FUSED3(FULL, RNG) do {                                                                                           \
-        const bool e1 = c->lds_L <= 256, n1 = c->lds_NL <= 256;                                                          \
-        if (e1 && n1) FUSED4(FULL, RNG, 1, 1); else if (e1) FUSED4(FULL, RNG, 1, 2);                                     \
-        else if (n1) FUSED4(FULL, RNG, 2, 1); else FUSED4(FULL, RNG, 2, 2);                                              \
-    } while (0)
+#define FUSED3(FULL, RNG) FUSED4(FULL, RNG, 1, 1)      /* L, NL <= 256 = threads: one staged element / node per lane (fep_host.h) */
+    if (c->lds_L > 256 || c->lds_NL > 256) return FEP_ESTATE;
     if (full) { if (c->p1_fused_rng) FUSED3(true, true); else FUSED3(true, false); }
     else { if (c->p1_fused_rng) FUSED3(false, true); else FUSED3(false, false); }
 #undef FUSED3

@@ -366,8 +366,10 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
     for (int64_t g = 0; g < n_wg; ++g) P.tdesc[(size_t)g * kDescInts + 3] |= (int32_t)(lists[g].size() << 4);   // staged elements of the tile
     P.C = (int)((cmax + 7) & ~(size_t)7);
     P.L = (int)((lmax + 1) & ~(size_t)1);
-    // 15 doubles per staged element; the staged kernels hold <= 2 elements and <= 4 gather codes per lane in registers
-    P.lds = lmax <= 2 * (size_t)TILE && cmax <= 4 * (size_t)TILE &&
+    // 15 doubles per staged element; the staged kernels hold ONE element and <= 4 gather codes per lane in registers.
+    // (A tile of B blocks over N nodes stages at most B - N elements — every staged element is a distinct neighbour
+    // relation of one of its nodes — and touches at most B nodes, so with B <= tile = threads both always fit.)
+    P.lds = lmax <= (size_t)TILE && cmax <= 4 * (size_t)TILE &&
             (size_t)P.L * 15 * sizeof(double) + (size_t)P.C * 2 <= 96 * 1024;
     if (!P.lds) return FEP_OK;
     const int64_t LP = P.L, CP = P.C;
@@ -458,7 +460,7 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
         nlmax = std::max(nlmax, nlists[g].size());
         P.staged_nodes_total += (int64_t)nlists[g].size();
     }
-    if (nlmax == 0 || nlmax > 2 * (size_t)TILE) { P.elnodes.clear(); return FEP_OK; }
+    if (nlmax == 0 || nlmax > (size_t)TILE) { P.elnodes.clear(); return FEP_OK; }
     {   // owner bits, in tile order
         std::vector<uint8_t> owned((size_t)n_e, 0);
         for (int64_t g = 0; g < n_wg; ++g)
