@@ -68,3 +68,15 @@ def relerr_rows(A, B):
         d = np.abs(np.asarray(A) - np.asarray(B)).max(axis=1)
         s = np.abs(np.asarray(B)).max(axis=1)
     return float(np.where(s > 0, d / np.where(s > 0, s, 1.0), d).max()) if d.size else 0.0
+
+
+@pytest.fixture(scope='session')
+def tsx_csv_dir(tmp_path_factory):
+    """coord.csv / elem.csv of the tsx-tunnel mesh in the reference's on-disk format (2 x n_n coordinates; 3 x n_e
+    vertex ids, 1-BASED; comma separated), written from the arrays recorded in tsx.npz — the files themselves are not
+    kept in the repository."""
+    g = load_golden('tsx')
+    d = tmp_path_factory.mktemp('tsx_csv')
+    np.savetxt(d / 'coord.csv', g['coord'], delimiter=',', fmt='%.17g')
+    np.savetxt(d / 'elem.csv', g['elem'] + 1, delimiter=',', fmt='%d')
+    return str(d)

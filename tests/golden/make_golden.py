@@ -503,18 +503,6 @@ def gen_tsx_p2p4(R, types=('P2', 'P4')):
              U_steps=Us[keep], steps=np.array(keep), U_mon=Us[:, 0, 40], F0=F0)
 
 
-def gen_tsx_csv(R):
-    """The reference's mesh DATA files (tsx-tunnel/coord.csv, elem.csv: 7 + 10 KB of numbers) as test fixtures of the
-    CSV reader (load_tsx_mesh, TSX:1687-1688)."""
-    import shutil
-    dst = os.path.join(OUT, 'tsx_csv')
-    os.makedirs(dst, exist_ok=True)
-    for f in ('coord.csv', 'elem.csv'):
-        shutil.copyfile(os.path.join(REF, 'tsx-tunnel', f), os.path.join(dst, f))
-        os.chmod(os.path.join(dst, f), 0o644)
-        print(f'tsx_csv/{f}  {os.path.getsize(os.path.join(dst, f)) / 1024:.1f} KiB')
-
-
 def gen_el(R):
     """Config 1: Elasticity2D P1 elastic K assembly (EL:368-477) on the square
     with a corner cut-out (EL:935), levels 1 and 3."""
@@ -544,7 +532,7 @@ def gen_el(R):
 if __name__ == '__main__':
     R = _load_reference()
     which = sys.argv[1:] or ['tables', 'mesh_dp', 'setup', 'retmap', 'hotpath', 'dp_trace', 'tsx', 'el', 'transform',
-                             'tsx_csv', 'dp_trace_types', 'tsx_p2p4']
+                             'dp_trace_types', 'tsx_p2p4']
     for w in which:
         print('==', w)
         globals()['gen_' + w](R)

@@ -176,19 +176,17 @@ def test_host_transform_vs_reference_golden(fep, t):
 
 
 @pytest.mark.parametrize('t', ['P1', 'P2', 'P4'])
-def test_load_tsx_mesh_from_csv(fep, t):
-    """coord.csv / elem.csv (the reference's data files, copied as fixtures) -> exactly what TSX:1687-1690 builds:
+def test_load_tsx_mesh_from_csv(fep, tsx_csv_dir, t):
+    """coord.csv / elem.csv in the reference's on-disk format (1-based vertex ids) -> exactly what TSX:1687-1690 builds:
     0-based elements, P2 / P4 midpoints with the reference's numbering (arrays recorded from the reference)."""
-    import os
-    from conftest import GOLDEN
     g = load_golden('tsx')
-    coord, elem = fep.load_tsx_mesh(os.path.join(GOLDEN, 'tsx_csv'), t)
+    coord, elem = fep.load_tsx_mesh(tsx_csv_dir, t)
     kc, ke = {'P1': ('coord', 'elem'), 'P2': ('p2_coord', 'p2_elem'), 'P4': ('p4_coord', 'p4_elem')}[t]
     assert coord.dtype == np.float64 and elem.dtype == np.int64 and elem.min() == 0
     assert np.array_equal(coord, g[kc]) and np.array_equal(elem, g[ke])
 
 
-def test_load_tsx_mesh_rejects_bad_files(fep, tmp_path):
+def test_load_tsx_mesh_rejects_bad_files(fep, tmp_path, tsx_csv_dir):
     np.savetxt(tmp_path / 'coord.csv', np.zeros((2, 3)), delimiter=',')
     np.savetxt(tmp_path / 'elem.csv', np.array([[1], [2], [4]]), delimiter=',', fmt='%d')      # node 4 of 3
     with pytest.raises(IndexError):
@@ -197,7 +195,7 @@ def test_load_tsx_mesh_rejects_bad_files(fep, tmp_path):
     with pytest.raises(ValueError):
         fep.load_tsx_mesh(str(tmp_path))
     with pytest.raises(ValueError):
-        fep.load_tsx_mesh(os.path.join(os.path.dirname(__file__), 'golden', 'tsx_csv'), 'Q1')
+        fep.load_tsx_mesh(tsx_csv_dir, 'Q1')
 
 
 def test_dump_free_dof_csv_roundtrip(fep, tmp_path):

@@ -68,15 +68,13 @@ def test_dp_driver_other_element_types_vs_reference_trace(fep, t, n_steps, n_acc
 
 
 @pytest.mark.parametrize('t', ['P2', 'P4'])
-def test_tsx_driver_on_the_demo_element_types_vs_reference_replay(fep, t):
+def test_tsx_driver_on_the_demo_element_types_vs_reference_replay(fep, tsx_csv_dir, t):
     """The TSX load-step sequence on the element types the reference's demo runs (tsx-tunnel/sandbox.py:3-4: P4; the
     driver only works for P2 / P4, TSX:1629-1633), against the replay recorded with the reference's own functions and
     dense solves (make_golden.py gen_tsx_p2p4): 17 steps, plastic-point counts, call count, displacements 1e-10."""
-    import os
-    from conftest import GOLDEN
     g = load_golden(f'tsx_{t.lower()}_trace')
     # the mesh comes from coord.csv / elem.csv + midpoints, as the reference's driver reads it (TSX:1687-1690)
-    h = fep.solve_tsx_tunnel(element_type=t, mesh_dir=os.path.join(GOLDEN, 'tsx_csv'))
+    h = fep.solve_tsx_tunnel(element_type=t, mesh_dir=tsx_csv_dir)
     assert len(h['zeta']) == 17 == len(g['zeta']) and np.allclose(h['zeta'], g['zeta'], rtol=0, atol=1e-15)
     assert h['n_plast'] == g['nplast'].tolist() and h['n_plast'][-1] > 0
     assert h['n_calls'] == int(g['n_calls'])
