@@ -495,7 +495,9 @@ inline int build_p1_plan(const Symbolic& S, int64_t n_e, int64_t n_n, const int3
     if (r != FEP_OK || opt.max_segs <= 1 || !P.lds || !P.pk) return r;
     P1Plan Q;
     r = build_p1_plan_segs(S, n_e, n_n, elem, opt, opt.max_segs, Q);
-    if (r == FEP_OK && Q.lds && Q.pk && (Q.fused || !P.fused) && Q.staged_total * 100 <= P.staged_total * 95) P = std::move(Q);
+    // (and must not lose a table compression the strips have: run-compressed lists are worth more than fewer slots)
+    if (r == FEP_OK && Q.lds && Q.pk && (Q.fused || !P.fused) && (Q.rng || !P.rng) && (Q.fused_rng || !P.fused_rng) &&
+        Q.staged_total * 100 <= P.staged_total * 95) P = std::move(Q);
     return FEP_OK;
 }
 
