@@ -30,6 +30,16 @@ struct fep_ctx {
                                                         // measured P2 / Q2 / P4 reduce kernel: 2: 0.406 / 0.376 / 0.654 ms, 4: 0.392 / 0.347 / 0.651,
                                                         // 6: 0.382 / 0.371 / 0.650, 8 (5 waves per SIMD): 0.432 / 0.425 / 0.733)
     bool kc_aos = false;                                // K_e half-blocks: all blocks of an element adjacent (AoS) or block-major (SoA)
+    // patch route of the element kernel (default; FEP_GEN_PATH=coo keeps the K_e round trip): fep_host.h, PatchPlan
+    bool patch = false;
+    int patch_eb = 0, patch_dbg = 0;
+    int lds_pad = 0;                                    // FEP_ELEM_LDS_PAD: extra LDS bytes per workgroup of element_kernel (occupancy experiments)
+    int64_t n_open = 0, n_fopen = 0;
+    int32_t *pt_desc = nullptr, *pt_plist = nullptr, *pt_pel = nullptr, *pt_pnodes = nullptr;
+    uint2 *pt_items = nullptr, *pt_fitems = nullptr;
+    uint16_t *pt_codes = nullptr, *pt_fcodes = nullptr;
+    uint4 *pt_fix = nullptr, *pt_ffix = nullptr;
+    double *Pc = nullptr, *Pf = nullptr;                // partial blocks / forces of the open items (scratch, rewritten by every step)
     bool elem_geo = true;                               // element_kernel: geometry from coordinates instead of the dphi arrays
     MatU matu{};                                        // homogeneous-material fast path (arrays not read)
     // device, static
@@ -319,7 +329,8 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
                         c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tdesc, c->tstart,
-                        c->wg_nlist, c->wg_nrng, c->el_nodes, c->slot_counts, c->pkc};
+                        c->wg_nlist, c->wg_nrng, c->el_nodes, c->slot_counts, c->pkc, c->pt_desc, c->pt_plist, c->pt_items,
+                        c->pt_fitems, c->pt_codes, c->pt_fcodes, c->pt_fix, c->pt_ffix, c->Pc, c->Pf, c->pt_pel, c->pt_pnodes};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -397,8 +408,6 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     CK(dmalloc(&c->weight, c->n_int));
     CK(dmalloc(&c->det, c->n_int));
     CK(dmalloc(&c->shear, c->n_int)); CK(dmalloc(&c->bulk, c->n_int)); CK(dmalloc(&c->eta, c->n_int)); CK(dmalloc(&c->c, c->n_int));
-    CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
-    CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
     // COO route: tiles of whole nodes with at most kBlock node-pair blocks (csr_reduce_kernel's work units)
     std::vector<int32_t> tstart_all;
     CK(fep_host::row_tiles(S, n_n, kBlock, tstart_all));
@@ -491,7 +500,58 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
     CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
-    if (!c->p1_node && !c->gn) {
+    if (const char* lp = std::getenv("FEP_ELEM_LDS_PAD")) c->lds_pad = std::max(0, std::atoi(lp));
+    int elem_eb = 1;
+    switch (elem_type) {
+        case FEP_P1: elem_eb = c->elem_geo ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB; break;
+        case FEP_P2: elem_eb = c->elem_geo ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB; break;
+        case FEP_Q1: elem_eb = c->elem_geo ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB; break;
+        case FEP_Q2: elem_eb = c->elem_geo ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB; break;
+        case FEP_P4: elem_eb = c->elem_geo ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB; break;
+    }
+    if (!c->p1_node && !c->gn && r == FEP_OK) {
+        // element route, default: the patch form (no K_e round trip through HBM); FEP_GEN_PATH=coo keeps the COO form
+        const char* gp = std::getenv("FEP_GEN_PATH");
+        if (!(gp && std::strcmp(gp, "coo") == 0)) {
+            fep_host::PatchPlan P;
+            fep_host::PatchOptions popt;
+            if (const char* po = std::getenv("FEP_PATCH_ORDER")) popt.order = std::strcmp(po, "consecutive") == 0 ? 0 : 1;
+            if (const char* pr = std::getenv("FEP_PATCH_OPEN")) popt.open_rows = std::strcmp(pr, "rows") == 0;
+            CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
+            if (r == FEP_OK && P.ok && std::getenv("FEP_VALIDATE_PLAN")) {
+                const int bad = fep_host::validate_patch_plan(P, S, n_p, n_e, n_n, elements_h);
+                if (bad) { std::fprintf(stderr, "[fep] patch plan fails check %d\n", bad); r = FEP_EINVAL; }
+            }
+            if (r == FEP_OK && P.ok) {
+                c->patch = true; c->patch_eb = P.eb; c->n_open = P.n_open; c->n_fopen = P.n_fopen;
+                if (const char* db = std::getenv("FEP_PATCH_DBG")) c->patch_dbg = std::atoi(db);
+                CK(upload(&c->pt_desc, P.pdesc.data(), (int64_t)P.pdesc.size()));
+                CK(upload(&c->pt_pel, P.pel.data(), (int64_t)P.pel.size()));
+                CK(upload(&c->pt_pnodes, P.pnodes.data(), (int64_t)P.pnodes.size()));
+                CK(upload(&c->pt_items, (const uint2*)P.items.data(), (int64_t)P.items.size()));
+                CK(upload(&c->pt_codes, P.codes.data(), (int64_t)P.codes.size()));
+                CK(upload(&c->pt_fitems, (const uint2*)P.fitems.data(), (int64_t)P.fitems.size()));
+                CK(upload(&c->pt_fcodes, P.fcodes.data(), (int64_t)P.fcodes.size()));
+                CK(upload(&c->pt_fix, (const uint4*)P.fix.data(), (int64_t)P.fix.size()));
+                CK(upload(&c->pt_ffix, (const uint4*)P.ffix.data(), (int64_t)P.ffix.size()));
+                CK(upload(&c->pt_plist, P.plist.data(), (int64_t)P.plist.size()));
+                CK(dmalloc(&c->Pc, 4 * P.n_part));
+                CK(dmalloc(&c->Pf, 2 * P.n_fpart));
+                static const bool verbose = std::getenv("FEP_VERBOSE") != nullptr;
+                if (verbose)
+                    std::fprintf(stderr, "[fep] patch plan: %lld patches of <= %d elements, %zu items (<= %d per patch), %lld open blocks of %lld, "
+                                 "%lld partials (%.2f per element), %lld open nodes\n", (long long)P.n_patch, P.eb, P.items.size(), P.max_items,
+                                 (long long)P.n_open, (long long)c->n_blk, (long long)P.n_part, (double)P.n_part / (double)n_e,
+                                 (long long)P.n_fopen);
+            }
+        }
+        c->n_count_blocks = (int)grid_for(n_e, elem_eb);
+    }
+    if (!c->patch) {
+        CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
+        CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
+    }
+    if (!c->p1_node && !c->gn && !c->patch) {
         // measured at ~1 M points per type (tools/elem_bench.py): the element-major layout pays for the 15-node element only
         // (P4: step 1.47 -> 1.35 ms; P2 0.96 -> 1.06, Q2 0.82 -> 0.94, Q1 0.22 -> 0.26: their stores lose coalescing)
         c->kc_aos = elem_type == FEP_P4;
@@ -525,15 +585,6 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         c->n_wg_p1 = (int)tstart_all.size() - 1;
         CK(dmalloc(&c->Kc, 4 * (int64_t)sym_block_count(n_p) * n_e));
         CK(dmalloc(&c->fe, 2 * (int64_t)n_p * n_e));
-        int eb = 1;
-        switch (elem_type) {
-            case FEP_P1: eb = c->elem_geo ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB; break;
-            case FEP_P2: eb = c->elem_geo ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB; break;
-            case FEP_Q1: eb = c->elem_geo ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB; break;
-            case FEP_Q2: eb = c->elem_geo ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB; break;
-            case FEP_P4: eb = c->elem_geo ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB; break;
-        }
-        c->n_count_blocks = (int)grid_for(n_e, eb);
     }
     CK(dmalloc(&c->blk_counts, c->n_count_blocks));
 #undef CK
@@ -637,12 +688,20 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
                           double* eout, double* s, double* ds, uint8_t* indp, uint2* blk_counts,
                           double* Kc, double* fe) {
     static_assert(ElemCfg<NP, NQ, false>::EB * (NQ > NP ? NQ : NP) <= kBlock, "one pass per phase");
-#define ELEM_LAUNCH(GEO)                                                                                                \
-    hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO>), dim3(grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)),          \
-                       dim3(kBlock), 0, st, c->n_e,                                                                     \
-                       c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,       \
-                       c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts, Kc, fe, c->kc_aos ? 1 : 0)
-    if (c->elem_geo) ELEM_LAUNCH(true); else ELEM_LAUNCH(false);
+    // patch route: Kc / fe carry the caller's CSR values / force (phase 3 writes them, fixup_kernel the open rest)
+    const PatchArgs pa{c->pt_desc, c->pt_pel, c->pt_pnodes, c->pt_items, c->pt_codes, c->pt_fitems, c->pt_fcodes, c->Pc, c->Pf,
+                       c->patch ? Kc : nullptr, c->patch ? fe : nullptr, c->patch_dbg};
+#define ELEM_LAUNCH(GEO, PATCH)                                                                                          \
+    do {                                                                                                                 \
+        if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO>::EB) return FEP_ESTATE;                             \
+        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH>), dim3(grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)), \
+                           dim3(kBlock), (size_t)c->lds_pad, st, c->n_e,                                                \
+                           c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,   \
+                           c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts,                       \
+                           PATCH ? nullptr : Kc, PATCH ? nullptr : fe, c->kc_aos ? 1 : 0, pa);                          \
+    } while (0)
+    if (c->patch) { if (c->elem_geo) ELEM_LAUNCH(true, true); else ELEM_LAUNCH(false, true); }
+    else { if (c->elem_geo) ELEM_LAUNCH(true, false); else ELEM_LAUNCH(false, false); }
 #undef ELEM_LAUNCH
     HIP_TRY(hipGetLastError());
     return FEP_OK;
@@ -690,6 +749,24 @@ static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_o
                            c->n_n, c->iptr, c->ilist, c->fe, f_out);
         HIP_TRY(hipGetLastError());
     }
+    FEP_TRY(prof_mark(c, st));
+    return FEP_OK;
+}
+
+// patch route, second kernel: open blocks / open nodes from the patches' partials (+ the branch counters on the side)
+static int launch_fixup(fep_ctx* c, hipStream_t st, double* k_data, double* f_out, unsigned long long* counts_d, bool* counts_done) {
+    if (counts_done) *counts_done = false;
+    FEP_TRY(prof_mark(c, st));
+    const unsigned nb_k = k_data ? grid_for(c->n_open, kBlock) : 0u;
+    const unsigned nb_f = f_out ? grid_for(c->n_fopen, kBlock) : 0u;
+    const unsigned grid = nb_k + nb_f + (counts_d ? 1u : 0u);
+    if (grid > 0) {
+        hipLaunchKernelGGL(fixup_kernel, dim3(grid), dim3(kBlock), 0, st, (int)nb_k, c->n_open, c->pt_fix, c->n_fopen, c->pt_ffix,
+                           c->pt_plist, c->Pc, c->Pf, k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d, c->patch_dbg);
+        HIP_TRY(hipGetLastError());
+        if (counts_done) *counts_done = counts_d != nullptr;
+    }
+    FEP_TRY(prof_mark(c, st));
     FEP_TRY(prof_mark(c, st));
     return FEP_OK;
 }
@@ -918,13 +995,17 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
         return counted ? FEP_OK : launch_counts(c, st, cnt);
     }
     FEP_TRY(prof_mark(c, st));
+    if (c->has_orphans && c->patch && f_out_d)                    // nodes of no element: no item writes their force
+        HIP_TRY(hipMemsetAsync(f_out_d, 0, (size_t)c->n_dof * sizeof(double), st));
 #define CALL(NP, NQ)                                                                                     \
     FEP_TRY((launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk, \
-                                          k_data_d ? c->Kc : nullptr, f_out_d ? c->fe : nullptr)))
+                                          c->patch ? k_data_d : (k_data_d ? c->Kc : nullptr),            \
+                                          c->patch ? f_out_d : (f_out_d ? c->fe : nullptr))))
     DISPATCH_ELEM(c->elem_type, CALL)
 #undef CALL
     bool counted = false;
-    FEP_TRY(launch_reduce(c, st, k_data_d, f_out_d, cnt, &counted));
+    if (c->patch) FEP_TRY(launch_fixup(c, st, k_data_d, f_out_d, cnt, &counted));
+    else FEP_TRY(launch_reduce(c, st, k_data_d, f_out_d, cnt, &counted));
     return counted ? FEP_OK : launch_counts(c, st, cnt);
 }
 
@@ -947,12 +1028,16 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
     }
     const E0 e0 = make_e0(nullptr);
     FEP_TRY(prof_mark(c, st));
+    if (c->has_orphans && c->patch && f_out_d)
+        HIP_TRY(hipMemsetAsync(f_out_d, 0, (size_t)c->n_dof * sizeof(double), st));
 #define CALL(NP, NQ)                                                                                         \
     FEP_TRY((launch_element<NP, NQ, false>(c, st, nullptr, e0, nullptr, 0, nullptr, const_cast<double*>(s_d), \
                                            const_cast<double*>(ds_d), nullptr, nullptr,                      \
-                                           k_data_d ? c->Kc : nullptr, f_out_d ? c->fe : nullptr)))
+                                           c->patch ? k_data_d : (k_data_d ? c->Kc : nullptr),               \
+                                           c->patch ? f_out_d : (f_out_d ? c->fe : nullptr))))
     DISPATCH_ELEM(c->elem_type, CALL)
 #undef CALL
+    if (c->patch) return launch_fixup(c, st, k_data_d, f_out_d, nullptr, nullptr);
     return launch_reduce(c, st, k_data_d, f_out_d);
 }
 

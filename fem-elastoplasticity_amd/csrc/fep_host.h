@@ -11,6 +11,7 @@
 //   aggregate        greedy aggregation of a node graph (multigrid setup, solver.py)
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -648,6 +649,515 @@ inline void build_gn_plan(const Symbolic& S, int n_p, int n_q, int64_t n_e, GnPl
         }
         return;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Patch plan of the element route (P2 / Q1 / Q2 / P4, and P1 with FEP_P1_PATH=coo): the element matrices never make
+// the round trip through HBM.
+//
+// A patch = the <= `eb` elements one workgroup of element_kernel processes: a chunk of the elements in the order of a
+// Hilbert curve through their centroids (compact in 2-D whatever the caller's numbering: what leaves a patch is
+// proportional to its perimeter), listed in ascending element id (`pel`, `pnodes`).  Only the grouping is internal: every
+// array the caller sees keeps its own element / point / node order.  The kernel leaves the stored half of every K_e
+// (sym_block_index) and the element force pairs in LDS; then one lane per ITEM sums, in ascending element order, the
+// contributions of ITS patch to one node-pair block of the CSR pattern:
+//   closed item  every contribution of the block lies inside the patch (always true for node pairs that share one
+//                element only: 12 of the 36 pairs of a P2 element, 153 of the 225 of a P4 element) -> the sum is the
+//                CSR block, written straight to its two rows;
+//   open item    the block also gets contributions from other patches (node pairs on a patch-boundary edge) -> the sum
+//                is a PARTIAL, written to slot `y` of a side buffer (32 bytes per slot, a patch's slots consecutive);
+//                fixup_kernel adds a block's partials in ascending patch order and writes the CSR block.
+//   (`open_rows`: every block whose ROW NODE has elements in several patches is open, so that whole CSR rows are
+//    written by one kernel — more partials, no partially written rows.)
+// Forces: the same with one item per node of the patch (closed: all incident elements inside the patch).
+// Deterministic (fixed order, no atomics); the association differs from the flat element order of the COO route
+// ((a+b+c) + (d+e+f) instead of a+b+c+d+e+f for a vertex on a patch boundary), so the two routes agree to rounding only.
+//
+//   pdesc   kPatchDescInts int32 per patch: item_off, n_items, code_off, n_codes, fitem_off, n_fitems, fcode_off, n_fcodes
+//   pel     eb int32 per patch: its elements, ascending, padded with -1;   pnodes  [patch][a][local element] node ids (0 padded)
+//   items   x: code offset in the patch:13 | (count-1):6 | degree of the row node:12 | open:1
+//           y: closed: position of the block's first row in double2 units (2*nptr[n] + slot); open: partial slot
+//   codes   uint16 (position of the stored block in LDS = idx*eb + local element) << 1 | transposed
+//   fitems  x: code offset:13 | (count-1):6 | open << 31;  y: node | force partial slot;   fcodes  a*eb + local element
+//   fix     per open block: x = position (as items.y), y = degree | count << 16, z = first partial slot,
+//           w = second partial slot (count <= 2) or offset into plist (count > 2: `count` slots, ascending patch)
+//   ffix    per open node:  x = node, y = count, z / w as above
+// ---------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+constexpr int kPatchDescInts = 8;
+
+struct PatchOptions {
+    int order = 1;                                      // 0: consecutive elements, 1: Hilbert curve through the centroids
+    bool open_rows = false;
+};
+
+struct PatchPlan {
+    bool ok = false;
+    int eb = 0, max_items = 0, max_fitems = 0;
+    int64_t n_patch = 0, n_open = 0, n_part = 0, n_fopen = 0, n_fpart = 0;
+    std::vector<int32_t> pdesc, plist, pel, pnodes;
+    std::vector<U2> items, fitems;
+    std::vector<uint16_t> codes, fcodes;
+    std::vector<U4> fix, ffix;
+};
+
+// where element_kernel keeps the block (a, b) of K_e (same function as fep::sym_block_index, block-major numbering)
+inline void patch_block_index(int n_p, int a, int b, int& idx, bool& transposed) {
+    const int j = b >= a ? b - a : b - a + n_p;
+    const bool direct = 2 * j < n_p || (2 * j == n_p && a < n_p / 2);
+    if (direct) { idx = j * n_p + a; transposed = false; }
+    else { idx = (n_p - j) * n_p + b; transposed = true; }
+}
+
+// position of (x, y), 16 bits each, along the Hilbert curve of order 16
+inline uint32_t hilbert_d(uint32_t x, uint32_t y) {
+    uint32_t d = 0;
+    for (uint32_t s = 1u << 15; s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 65535u - x; y = 65535u - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
+// pel / patch_of for the chosen grouping (coords: planar x[n_n], y[n_n]; may be NULL -> consecutive elements)
+inline void patch_grouping(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem, const double* coords, int eb, int order,
+                           std::vector<int32_t>& pel, std::vector<int32_t>& patch_of) {
+    const int64_t n_patch = (n_e + eb - 1) / eb;
+    pel.assign((size_t)(n_patch * eb), -1);
+    patch_of.resize((size_t)n_e);
+    std::vector<int32_t> seq((size_t)n_e);
+    for (int64_t e = 0; e < n_e; ++e) seq[e] = (int32_t)e;
+    if (order == 1 && coords && n_e > eb) {
+        double lo[2] = {coords[0], coords[n_n]}, hi[2] = {coords[0], coords[n_n]};
+        for (int64_t n = 0; n < n_n; ++n)
+            for (int k = 0; k < 2; ++k) { const double v = coords[k * n_n + n]; lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); }
+        const double ext = std::max(hi[0] - lo[0], hi[1] - lo[1]);
+        const double sc = ext > 0 ? 65535.0 / ext : 0.0;                     // one scale for both axes: square cells stay square
+        std::vector<uint64_t> key((size_t)n_e);
+        parallel_chunks(n_e, [&](int64_t a0, int64_t a1, int) {
+            for (int64_t e = a0; e < a1; ++e) {
+                double cx = 0.0, cy = 0.0;
+                for (int a = 0; a < n_p; ++a) { const int32_t nd = elem[(int64_t)a * n_e + e]; cx += coords[nd]; cy += coords[n_n + nd]; }
+                const double qx = (cx / n_p - lo[0]) * sc, qy = (cy / n_p - lo[1]) * sc;
+                const uint32_t ix = (uint32_t)std::min(65535.0, std::max(0.0, qx)), iy = (uint32_t)std::min(65535.0, std::max(0.0, qy));
+                key[e] = ((uint64_t)hilbert_d(ix, iy) << 32) | (uint32_t)e;
+            }
+        });
+        std::sort(key.begin(), key.end());
+        for (int64_t i = 0; i < n_e; ++i) seq[i] = (int32_t)(key[i] & 0xffffffffu);
+    }
+    for (int64_t p = 0; p < n_patch; ++p) {
+        const int64_t i0 = p * eb, i1 = std::min<int64_t>(n_e, i0 + eb);
+        std::sort(seq.begin() + i0, seq.begin() + i1);                        // a patch lists its elements in ascending id
+        for (int64_t i = i0; i < i1; ++i) { pel[(size_t)i] = seq[i]; patch_of[seq[i]] = (int32_t)p; }
+    }
+}
+
+inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n, const int32_t* elem, const double* coords,
+                            int eb, const PatchOptions& opt, PatchPlan& P) {
+    P = PatchPlan();
+    P.eb = eb;
+    const int nj = n_p / 2 + 1;
+    if (eb < 1 || (int64_t)n_p * n_p * eb > 8192 || (int64_t)nj * n_p * eb >= 32768) return FEP_OK;       // field widths: plan not usable
+    const int64_t n_blk = (int64_t)S.ncol.size();
+    const int64_t n_patch = (n_e + eb - 1) / eb;
+    P.n_patch = n_patch;
+    std::vector<int32_t> patch_of;
+    patch_grouping(n_p, n_e, n_n, elem, coords, eb, opt.order, P.pel, patch_of);
+    P.pnodes.assign((size_t)(n_patch * n_p * eb), 0);
+    parallel_chunks(n_patch, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t p = lo; p < hi; ++p)
+            for (int el = 0; el < eb; ++el) {
+                const int32_t e = P.pel[(size_t)(p * eb + el)];
+                if (e < 0) continue;
+                for (int a = 0; a < n_p; ++a) P.pnodes[(size_t)((p * n_p + a) * eb + el)] = elem[(int64_t)a * n_e + e];
+            }
+    });
+    // pass A: how many patches contribute to every node / block
+    std::vector<uint8_t> npb((size_t)n_blk, 0), npn((size_t)n_n, 0);
+    std::atomic<int> bad{0};
+    auto distinct = [&](const int32_t* list, int32_t beg, int32_t end, std::vector<int32_t>& buf) {
+        buf.clear();
+        for (int32_t t = beg; t < end; ++t) buf.push_back(patch_of[(size_t)((int64_t)list[t] % n_e)]);
+        std::sort(buf.begin(), buf.end());
+        buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+    };
+    parallel_chunks(n_n, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> buf;
+        for (int64_t n = lo; n < hi; ++n) {
+            distinct(S.ilist.data(), S.iptr[n], S.iptr[n + 1], buf);
+            if (buf.size() > 255) { bad.store(1, std::memory_order_relaxed); buf.resize(255); }
+            npn[n] = (uint8_t)buf.size();
+            for (int32_t b = S.nptr[n]; b < S.nptr[n + 1]; ++b) {
+                if (npn[n] < 2) { npb[b] = 1; continue; }                     // all elements of the row node in one patch
+                distinct(S.perm.data(), S.segptr[b], S.segptr[b + 1], buf);
+                npb[b] = (uint8_t)std::min<size_t>(buf.size(), 255);
+            }
+        }
+    });
+    if (bad.load()) return FEP_OK;
+    // open blocks / nodes: index, table entries, plist offsets
+    auto is_open = [&](int64_t n, int32_t b) { return opt.open_rows ? npn[n] >= 2 : npb[b] >= 2; };
+    std::vector<int32_t> open_idx((size_t)n_blk, -1), fopen_idx((size_t)n_n, -1);
+    int64_t n_plist = 0;
+    for (int64_t n = 0; n < n_n; ++n) {
+        const uint32_t deg = (uint32_t)(S.nptr[n + 1] - S.nptr[n]);
+        if (deg > 4095) return FEP_OK;
+        for (int32_t b = S.nptr[n]; b < S.nptr[n + 1]; ++b) {
+            if (!is_open(n, b)) continue;
+            open_idx[b] = (int32_t)P.fix.size();
+            U4 f{(uint32_t)(2 * (int64_t)S.nptr[n] + (b - S.nptr[n])), deg | ((uint32_t)npb[b] << 16), 0u, 0u};
+            if (npb[b] > 2) { f.w = (uint32_t)n_plist; n_plist += npb[b]; }
+            P.fix.push_back(f);
+        }
+        if (npn[n] >= 2) {
+            fopen_idx[n] = (int32_t)P.ffix.size();
+            U4 f{(uint32_t)n, (uint32_t)npn[n], 0u, 0u};
+            if (npn[n] > 2) { f.w = (uint32_t)n_plist; n_plist += npn[n]; }
+            P.ffix.push_back(f);
+        }
+        if (n_plist >= INT32_MAX / 2) return FEP_ERANGE;
+    }
+    P.n_open = (int64_t)P.fix.size();
+    P.n_fopen = (int64_t)P.ffix.size();
+    P.plist.assign((size_t)n_plist, -1);
+    // pass B: the patches' items, worker-local, then concatenated
+    struct Out {
+        std::vector<int32_t> pdesc;                      // local offsets
+        std::vector<U2> items, fitems;
+        std::vector<uint16_t> codes, fcodes;
+        std::vector<int32_t> open_b, open_p, fopen_n, fopen_p;   // per local partial slot: its block / node and patch
+        int max_items = 0, max_fitems = 0, fail = 0;
+    };
+    const int nw = (int)std::max<int64_t>(1, std::min<int64_t>(worker_count(), n_patch));
+    std::vector<Out> outs((size_t)nw);
+    parallel_chunks(n_patch, [&](int64_t lo, int64_t hi, int w) {
+        Out& O = outs[(size_t)w];
+        struct Tup { int32_t key; uint16_t code; };
+        std::vector<Tup> tup, ftup;
+        std::vector<U2> open_items;
+        std::vector<uint16_t> open_codes;
+        std::vector<int32_t> open_keys;
+        for (int64_t p = lo; p < hi; ++p) {
+            const int32_t* pe = P.pel.data() + p * eb;
+            int nel = 0;
+            while (nel < eb && pe[nel] >= 0) ++nel;
+            tup.clear(); ftup.clear();
+            for (int el = 0; el < nel; ++el)
+                for (int a = 0; a < n_p; ++a) {
+                    const int32_t na = elem[(int64_t)a * n_e + pe[el]];
+                    ftup.push_back(Tup{na, (uint16_t)(a * eb + el)});
+                    const int32_t* row = S.ncol.data() + S.nptr[na];
+                    const int32_t* row_end = S.ncol.data() + S.nptr[na + 1];
+                    for (int b = 0; b < n_p; ++b) {
+                        const int32_t nb = elem[(int64_t)b * n_e + pe[el]];
+                        const int32_t blk = (int32_t)(S.nptr[na] + (std::lower_bound(row, row_end, nb) - row));
+                        int idx; bool tr;
+                        patch_block_index(n_p, a, b, idx, tr);
+                        tup.push_back(Tup{blk, (uint16_t)(((idx * eb + el) << 1) | (tr ? 1 : 0))});
+                    }
+                }
+            // (el, a, b) generation order = ascending element id: the stable sorts keep it inside every block / node
+            std::stable_sort(tup.begin(), tup.end(), [](const Tup& x, const Tup& y) { return x.key < y.key; });
+            std::stable_sort(ftup.begin(), ftup.end(), [](const Tup& x, const Tup& y) { return x.key < y.key; });
+            const size_t item0 = O.items.size(), code0 = O.codes.size(), fitem0 = O.fitems.size(), fcode0 = O.fcodes.size();
+            open_items.clear(); open_codes.clear(); open_keys.clear();
+            // closed items first (their codes too), open items behind them; both in ascending block order
+            for (size_t i = 0; i < tup.size();) {
+                size_t j = i + 1;
+                while (j < tup.size() && tup[j].key == tup[i].key) ++j;
+                const int32_t b = tup[i].key;
+                const uint32_t cnt = (uint32_t)(j - i);
+                if (cnt > 64) { O.fail = 1; break; }
+                const bool all_here = (int32_t)cnt == S.segptr[b + 1] - S.segptr[b];
+                if ((npb[b] < 2) != all_here) { O.fail = 2; break; }
+                if (open_idx[b] < 0) {
+                    const uint32_t deg = S.meta[b] >> 16, slot = S.meta[b] & 0x7fffu;
+                    O.items.push_back(U2{(uint32_t)(O.codes.size() - code0) | ((cnt - 1) << 13) | (deg << 19),
+                                         (uint32_t)(2 * (int64_t)(b - (int32_t)slot) + slot)});
+                    for (size_t k = i; k < j; ++k) O.codes.push_back(tup[k].code);
+                } else {
+                    open_items.push_back(U2{(uint32_t)open_codes.size() | ((cnt - 1) << 13) | (1u << 31), 0u});
+                    for (size_t k = i; k < j; ++k) open_codes.push_back(tup[k].code);
+                    open_keys.push_back(b);
+                }
+                i = j;
+            }
+            if (O.fail) break;
+            const uint32_t shift = (uint32_t)(O.codes.size() - code0);
+            for (size_t i = 0; i < open_items.size(); ++i) {
+                U2 it = open_items[i];
+                it.x += shift;                                               // code offset: behind the closed items' codes
+                it.y = (uint32_t)O.open_b.size();                            // worker-local slot, rebased after the join
+                O.items.push_back(it);
+                O.open_b.push_back(open_keys[i]);
+                O.open_p.push_back((int32_t)p);
+            }
+            O.codes.insert(O.codes.end(), open_codes.begin(), open_codes.end());
+            const int32_t n_codes_p = (int32_t)(O.codes.size() - code0);
+            if (O.codes.size() & 1) O.codes.push_back(0);                    // every patch's codes start at an even offset (32-bit loads)
+            for (size_t i = 0; i < ftup.size();) {
+                size_t j = i + 1;
+                while (j < ftup.size() && ftup[j].key == ftup[i].key) ++j;
+                const int32_t n = ftup[i].key;
+                const uint32_t cnt = (uint32_t)(j - i);
+                if (cnt > 64) { O.fail = 1; break; }
+                const bool closed = (int32_t)cnt == S.iptr[n + 1] - S.iptr[n];
+                if ((npn[n] < 2) != closed) { O.fail = 2; break; }
+                uint32_t y = (uint32_t)n;
+                if (!closed) { y = (uint32_t)O.fopen_n.size(); O.fopen_n.push_back(n); O.fopen_p.push_back((int32_t)p); }
+                O.fitems.push_back(U2{(uint32_t)(O.fcodes.size() - fcode0) | ((cnt - 1) << 13) | (closed ? 0u : 1u << 31), y});
+                for (size_t k = i; k < j; ++k) O.fcodes.push_back(ftup[k].code);
+                i = j;
+            }
+            if (O.fail) break;
+            const int32_t n_fcodes_p = (int32_t)(O.fcodes.size() - fcode0);
+            if (O.fcodes.size() & 1) O.fcodes.push_back(0);
+            const int32_t d[kPatchDescInts] = {(int32_t)item0, (int32_t)(O.items.size() - item0), (int32_t)code0, n_codes_p,
+                                               (int32_t)fitem0, (int32_t)(O.fitems.size() - fitem0), (int32_t)fcode0, n_fcodes_p};
+            O.pdesc.insert(O.pdesc.end(), d, d + kPatchDescInts);
+            O.max_items = std::max(O.max_items, d[1]);
+            O.max_fitems = std::max(O.max_fitems, d[5]);
+            if (O.items.size() >= (size_t)INT32_MAX / 2 || O.codes.size() >= (size_t)INT32_MAX / 2) { O.fail = 3; break; }
+        }
+    });
+    // bases of every worker's pieces
+    std::vector<int64_t> bi(nw + 1, 0), bc(nw + 1, 0), bfi(nw + 1, 0), bfc(nw + 1, 0), bs(nw + 1, 0), bfs(nw + 1, 0);
+    for (int w = 0; w < nw; ++w) {
+        const Out& O = outs[(size_t)w];
+        if (O.fail == 3) return FEP_ERANGE;
+        if (O.fail == 2) return FEP_EINVAL;              // inconsistent with the symbolic phase: a bug, not a property of the mesh
+        if (O.fail) return FEP_OK;                       // a field does not fit: no plan, the caller keeps the COO route
+        bi[w + 1] = bi[w] + (int64_t)O.items.size(); bc[w + 1] = bc[w] + (int64_t)O.codes.size();
+        bfi[w + 1] = bfi[w] + (int64_t)O.fitems.size(); bfc[w + 1] = bfc[w] + (int64_t)O.fcodes.size();
+        bs[w + 1] = bs[w] + (int64_t)O.open_b.size(); bfs[w + 1] = bfs[w] + (int64_t)O.fopen_n.size();
+        P.max_items = std::max(P.max_items, O.max_items);
+        P.max_fitems = std::max(P.max_fitems, O.max_fitems);
+    }
+    if (bi[nw] >= INT32_MAX / 2 || bc[nw] >= INT32_MAX / 2 || bs[nw] >= INT32_MAX / 4) return FEP_ERANGE;
+    P.items.resize((size_t)bi[nw]); P.codes.resize((size_t)bc[nw] + 8, 0);
+    P.fitems.resize((size_t)bfi[nw]); P.fcodes.resize((size_t)bfc[nw] + 8, 0);
+    P.pdesc.resize((size_t)n_patch * kPatchDescInts);
+    P.n_part = bs[nw]; P.n_fpart = bfs[nw];
+    std::vector<std::thread> th;
+    auto finish = [&](int w) {
+        Out& O = outs[(size_t)w];
+        for (U2& it : O.items) if (it.x >> 31) it.y += (uint32_t)bs[w];
+        for (U2& it : O.fitems) if (it.x >> 31) it.y += (uint32_t)bfs[w];
+        std::copy(O.items.begin(), O.items.end(), P.items.begin() + bi[w]);
+        std::copy(O.codes.begin(), O.codes.end(), P.codes.begin() + bc[w]);
+        std::copy(O.fitems.begin(), O.fitems.end(), P.fitems.begin() + bfi[w]);
+        std::copy(O.fcodes.begin(), O.fcodes.end(), P.fcodes.begin() + bfc[w]);
+        const int64_t p0 = n_patch * w / nw;
+        for (size_t i = 0; i < O.pdesc.size(); i += kPatchDescInts) {
+            int32_t* d = P.pdesc.data() + (p0 * kPatchDescInts + (int64_t)i);
+            std::copy(O.pdesc.begin() + i, O.pdesc.begin() + i + kPatchDescInts, d);
+            d[0] += (int32_t)bi[w]; d[2] += (int32_t)bc[w]; d[4] += (int32_t)bfi[w]; d[6] += (int32_t)bfc[w];
+        }
+        // the fix-up tables: slot of patch p in its block's / node's list = rank of p among the contributing patches
+        std::vector<int32_t> buf;
+        for (size_t s = 0; s < O.open_b.size(); ++s) {
+            const int32_t b = O.open_b[s], p = O.open_p[s];
+            distinct(S.perm.data(), S.segptr[b], S.segptr[b + 1], buf);
+            const int rank = (int)(std::lower_bound(buf.begin(), buf.end(), p) - buf.begin());
+            U4& f = P.fix[(size_t)open_idx[b]];
+            const uint32_t slot = (uint32_t)(bs[w] + (int64_t)s);
+            if ((f.y >> 16) > 2) { P.plist[(size_t)f.w + rank] = (int32_t)slot; if (rank == 0) f.z = slot; }
+            else if (rank == 0) f.z = slot; else f.w = slot;
+        }
+        for (size_t s = 0; s < O.fopen_n.size(); ++s) {
+            const int32_t n = O.fopen_n[s], p = O.fopen_p[s];
+            distinct(S.ilist.data(), S.iptr[n], S.iptr[n + 1], buf);
+            const int rank = (int)(std::lower_bound(buf.begin(), buf.end(), p) - buf.begin());
+            U4& f = P.ffix[(size_t)fopen_idx[n]];
+            const uint32_t slot = (uint32_t)(bfs[w] + (int64_t)s);
+            if (f.y > 2) { P.plist[(size_t)f.w + rank] = (int32_t)slot; if (rank == 0) f.z = slot; }
+            else if (rank == 0) f.z = slot; else f.w = slot;
+        }
+    };
+    // (two workers never touch the same fix entry field: a block's partials come from different patches, each patch
+    // belongs to one worker and writes its own rank)
+    for (int w = 1; w < nw; ++w) {
+        try { th.emplace_back(finish, w); } catch (const std::system_error&) { finish(w); }
+    }
+    finish(0);
+    for (auto& t : th) t.join();
+    P.ok = true;
+    return FEP_OK;
+}
+
+// Consistency of a patch plan with the symbolic phase: replays every block's / node's sum from the plan (closed items,
+// or the partials of its fix-up entry in list order) and compares the (element, a, b) contributions with
+// Symbolic::perm / ilist (same multiset; ascending element inside every item); every CSR block, node, partial slot is
+// produced exactly once; every element belongs to exactly one patch; every index the kernels form stays inside its
+// table or LDS region.  Returns 0 or the number of the first failed check.
+inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, int64_t n_e, int64_t n_n, const int32_t* elem) {
+    if (!P.ok) return 0;
+    const int eb = P.eb, nj = n_p / 2 + 1;
+    const int64_t n_blk = (int64_t)S.ncol.size();
+    if ((int64_t)P.pdesc.size() != P.n_patch * kPatchDescInts || P.n_patch != (n_e + eb - 1) / eb) return 1;
+    if ((int64_t)P.pel.size() != P.n_patch * eb || (int64_t)P.pnodes.size() != P.n_patch * n_p * eb) return 1;
+    {
+        std::vector<uint8_t> owned((size_t)n_e, 0);
+        for (int64_t p = 0; p < P.n_patch; ++p)
+            for (int el = 0; el < eb; ++el) {
+                const int32_t e = P.pel[(size_t)(p * eb + el)];
+                if (e < 0) { for (int k = el; k < eb; ++k) if (P.pel[(size_t)(p * eb + k)] >= 0) return 35; break; }
+                if (e >= n_e || owned[e] || (el > 0 && e <= P.pel[(size_t)(p * eb + el - 1)])) return 35;
+                owned[e] = 1;
+                for (int a = 0; a < n_p; ++a) if (P.pnodes[(size_t)((p * n_p + a) * eb + el)] != elem[(int64_t)a * n_e + e]) return 36;
+            }
+        for (uint8_t v : owned) if (!v) return 37;
+        for (int32_t v : P.pnodes) if (v < 0 || v >= n_n) return 36;
+    }
+    // stored block (idx, transposed) -> (a, b)
+    std::vector<int> ab_of((size_t)2 * nj * n_p, -1);
+    for (int a = 0; a < n_p; ++a)
+        for (int b = 0; b < n_p; ++b) {
+            int idx; bool tr;
+            patch_block_index(n_p, a, b, idx, tr);
+            if (idx < 0 || idx >= nj * n_p) return 2;
+            if (a != b || !tr) ab_of[(size_t)2 * idx + (tr ? 1 : 0)] = a * n_p + b;
+        }
+    std::vector<std::vector<int32_t>> part_seq((size_t)P.n_part), fpart_seq((size_t)P.n_fpart);   // contributions of every partial
+    std::vector<uint8_t> part_seen((size_t)P.n_part, 0), fpart_seen((size_t)P.n_fpart, 0);
+    std::vector<uint8_t> blk_seen((size_t)n_blk, 0), node_seen((size_t)n_n, 0);
+    int64_t total = 0, ftotal = 0;
+    auto ascending = [&](const std::vector<int32_t>& q) {                    // by element, then (a, b)
+        for (size_t k = 1; k < q.size(); ++k) {
+            const int64_t e0 = q[k - 1] % n_e, e1 = q[k] % n_e;
+            if (e1 < e0 || (e1 == e0 && q[k] <= q[k - 1])) return false;
+        }
+        return true;
+    };
+    auto same_set = [&](std::vector<int32_t> got, const int32_t* ref, size_t n) {
+        if (got.size() != n) return false;
+        std::vector<int32_t> want(ref, ref + n);
+        std::sort(got.begin(), got.end()); std::sort(want.begin(), want.end());
+        return got == want;
+    };
+    for (int64_t p = 0; p < P.n_patch; ++p) {
+        const int32_t* d = P.pdesc.data() + p * kPatchDescInts;
+        const int32_t* pe = P.pel.data() + p * eb;
+        int nel = 0;
+        while (nel < eb && pe[nel] >= 0) ++nel;
+        if (d[0] < 0 || d[0] + (int64_t)d[1] > (int64_t)P.items.size() || d[2] < 0 || d[2] + (int64_t)d[3] + 8 > (int64_t)P.codes.size()) return 3;
+        if (d[4] < 0 || d[4] + (int64_t)d[5] > (int64_t)P.fitems.size() || d[6] < 0 || d[6] + (int64_t)d[7] + 8 > (int64_t)P.fcodes.size()) return 3;
+        if (d[3] != n_p * n_p * nel || d[7] != n_p * nel || d[1] > P.max_items || d[5] > P.max_fitems || (d[2] & 1) || (d[6] & 1)) return 4;
+        std::vector<int32_t> seq;
+        for (int32_t i = 0; i < d[1]; ++i) {
+            const U2 it = P.items[(size_t)d[0] + i];
+            const int off = (int)(it.x & 8191u), cnt = (int)((it.x >> 13) & 63u) + 1, deg = (int)((it.x >> 19) & 4095u);
+            const bool open = it.x >> 31;
+            if (off + cnt > d[3]) return 5;
+            seq.clear();
+            for (int k = 0; k < cnt; ++k) {
+                const unsigned code = P.codes[(size_t)d[2] + off + k];
+                const int pos = (int)(code >> 1), idx = pos / eb, el = pos % eb;
+                if (idx >= nj * n_p || el >= nel) return 6;
+                const int ab = ab_of[(size_t)2 * idx + (code & 1u)];
+                if (ab < 0) return 7;
+                seq.push_back((int32_t)((int64_t)ab * n_e + pe[el]));
+            }
+            if (!ascending(seq)) return 38;
+            total += cnt;
+            if (open) {
+                if (it.y >= (uint32_t)P.n_part || part_seen[it.y]) return 8;
+                part_seen[it.y] = 1;
+                part_seq[it.y] = seq;
+            } else {
+                // position -> block: row node n with 2*nptr[n] <= y < 2*nptr[n] + deg
+                const int64_t y = it.y;
+                const int64_t n = std::upper_bound(S.nptr.begin(), S.nptr.end(), (int32_t)(y / 2)) - S.nptr.begin() - 1;
+                if (n < 0 || n >= n_n) return 9;
+                const int64_t slot = y - 2 * (int64_t)S.nptr[n];
+                if (slot < 0 || slot >= S.nptr[n + 1] - S.nptr[n] || deg != S.nptr[n + 1] - S.nptr[n]) return 9;
+                const int64_t b = S.nptr[n] + slot;
+                if (blk_seen[b]) return 10;
+                blk_seen[b] = 1;
+                if (!same_set(seq, S.perm.data() + S.segptr[b], (size_t)(S.segptr[b + 1] - S.segptr[b]))) return 12;
+            }
+        }
+        for (int32_t i = 0; i < d[5]; ++i) {
+            const U2 it = P.fitems[(size_t)d[4] + i];
+            const int off = (int)(it.x & 8191u), cnt = (int)((it.x >> 13) & 63u) + 1;
+            const bool open = it.x >> 31;
+            if (off + cnt > d[7]) return 13;
+            seq.clear();
+            for (int k = 0; k < cnt; ++k) {
+                const unsigned code = P.fcodes[(size_t)d[6] + off + k];
+                const int a = (int)code / eb, el = (int)code % eb;
+                if (a >= n_p || el >= nel) return 14;
+                seq.push_back((int32_t)((int64_t)a * n_e + pe[el]));
+            }
+            if (!ascending(seq)) return 38;
+            ftotal += cnt;
+            if (open) {
+                if (it.y >= (uint32_t)P.n_fpart || fpart_seen[it.y]) return 15;
+                fpart_seen[it.y] = 1;
+                fpart_seq[it.y] = seq;
+            } else {
+                const int64_t n = it.y;
+                if (n >= n_n || node_seen[n]) return 16;
+                node_seen[n] = 1;
+                if (!same_set(seq, S.ilist.data() + S.iptr[n], (size_t)(S.iptr[n + 1] - S.iptr[n]))) return 18;
+            }
+        }
+    }
+    if (total != (int64_t)S.perm.size() || ftotal != (int64_t)S.ilist.size()) return 19;
+    for (uint8_t v : part_seen) if (!v) return 20;
+    for (uint8_t v : fpart_seen) if (!v) return 20;
+    std::vector<uint8_t> slot_used((size_t)P.n_part, 0), fslot_used((size_t)P.n_fpart, 0);
+    auto slots_of = [&](const U4& f, int cnt, std::vector<int64_t>& out) {
+        out.clear();
+        if (cnt <= 2) { out.push_back(f.z); if (cnt == 2) out.push_back(f.w); return true; }
+        if ((int64_t)f.w + cnt > (int64_t)P.plist.size()) return false;
+        for (int k = 0; k < cnt; ++k) out.push_back(P.plist[(size_t)f.w + k]);
+        return out[0] == (int64_t)f.z;
+    };
+    std::vector<int64_t> sl;
+    std::vector<int32_t> all;
+    for (const U4& f : P.fix) {
+        const int cnt = (int)(f.y >> 16), deg = (int)(f.y & 0xffffu);
+        if (cnt < 1 || !slots_of(f, cnt, sl)) return 21;
+        const int64_t n = std::upper_bound(S.nptr.begin(), S.nptr.end(), (int32_t)(f.x / 2)) - S.nptr.begin() - 1;
+        if (n < 0 || n >= n_n || deg != S.nptr[n + 1] - S.nptr[n]) return 22;
+        const int64_t slot = (int64_t)f.x - 2 * (int64_t)S.nptr[n];
+        if (slot < 0 || slot >= deg) return 22;
+        const int64_t b = S.nptr[n] + slot;
+        if (blk_seen[b]) return 23;
+        blk_seen[b] = 1;
+        all.clear();
+        for (int64_t s : sl) {
+            if (s < 0 || s >= P.n_part || slot_used[s]) return 24;
+            slot_used[s] = 1;
+            all.insert(all.end(), part_seq[(size_t)s].begin(), part_seq[(size_t)s].end());
+        }
+        if (!same_set(all, S.perm.data() + S.segptr[b], (size_t)(S.segptr[b + 1] - S.segptr[b]))) return 25;
+    }
+    for (const U4& f : P.ffix) {
+        const int cnt = (int)f.y;
+        if (cnt < 2 || !slots_of(f, cnt, sl)) return 27;
+        const int64_t n = f.x;
+        if (n >= n_n || node_seen[n]) return 28;
+        node_seen[n] = 1;
+        all.clear();
+        for (int64_t s : sl) {
+            if (s < 0 || s >= P.n_fpart || fslot_used[s]) return 29;
+            fslot_used[s] = 1;
+            all.insert(all.end(), fpart_seq[(size_t)s].begin(), fpart_seq[(size_t)s].end());
+        }
+        if (!same_set(all, S.ilist.data() + S.iptr[n], (size_t)(S.iptr[n + 1] - S.iptr[n]))) return 30;
+    }
+    for (int64_t b = 0; b < n_blk; ++b) if (!blk_seen[b]) return 32;
+    for (int64_t n = 0; n < n_n; ++n) if (!node_seen[n] && S.iptr[n + 1] > S.iptr[n]) return 33;
+    for (uint8_t v : slot_used) if (!v) return 34;
+    for (uint8_t v : fslot_used) if (!v) return 34;
+    return 0;
 }
 
 // Greedy aggregation of a node graph in CSR (smoothed-aggregation multigrid setup): agg_out[i] in [0, *n_agg_out).

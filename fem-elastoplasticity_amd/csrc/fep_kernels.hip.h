@@ -290,12 +290,37 @@ template <int NP, int NQ, bool GEO = false> struct ElemCfg {
     static constexpr int EB0 = (kBlock / maxpq) >= 64 ? 64 : ((kBlock / maxpq) >= 32 ? 32 : (kBlock / maxpq));
     // with the coordinate staging of GEO the big elements take fewer per workgroup, so that the LDS still admits
     // as many resident workgroups as without it (P2: 4 per CU, Q2: 3)
-    static constexpr int EB = !GEO ? EB0 : (NP == 6 && NQ == 7) ? 28 : (NP == 8 && NQ == 9) ? 24 : EB0;
+    // (the 15-node element: 16 instead of 17, so that two workgroups with their gather codes fit a CU's LDS)
+    static constexpr int EB = NP == 15 ? 16 : !GEO ? EB0 : (NP == 6 && NQ == 7) ? 28 : (NP == 8 && NQ == 9) ? 24 : EB0;
     static constexpr int NQS = NQ | 1;                  // odd LDS stride: conflict-free ds_read_b64 over elements
     static constexpr int NPTS = EB * NQS;
+    static constexpr int NJ = NP / 2 + 1;               // stored node-pair blocks (a, a+j mod NP) per local node
+    // LDS image in doubles.  Phases 1-2: dphi (2*NP rows), w*DS (6), w*S (3) per point, then the per-element node
+    // coordinates / displacements and the reference-element tables.  Phase 3 (patch route) re-uses the same memory:
+    // stored K_e blocks (NJ*NP*EB x 4), force pairs (NP*EB x 2), the patch's gather codes (uint16).
+    static constexpr int kPts = (2 * NP + 9) * NPTS;
+    static constexpr int kXY = 2 * NP * EB;             // one double2 per (local node, element)
+    static constexpr int kTab = 2 * NP * NQ + NQ + (NQ & 1);
+    static constexpr int kKl = 4 * NJ * NP * EB, kFl = 2 * NP * EB;
+    static constexpr int kCodes = (NP * NP * EB + 3) / 4 + 1, kFcodes = (NP * EB + 3) / 4 + 1;    // doubles holding the uint16 codes
+    static constexpr int kPhase3 = kKl + kFl + kCodes + kFcodes;
 };
 
-template <int NP, int NQ, bool FROM_U, bool GEO>
+// Patch route (PATCH = true; fep_host.h, PatchPlan): the workgroup's EB elements are a patch.  Phase 2 leaves the stored
+// K_e blocks and the force pairs in LDS instead of HBM; phase 3, one lane per item, sums the patch's contributions to one
+// node-pair block (force: one node) in the fixed (e, a, b) order and writes either the finished CSR block / nodal force
+// (every contribution inside the patch) or a partial for fixup_kernel.  No K_e round trip through HBM.
+struct PatchArgs {
+    const int32_t* pdesc;                               // 8 ints per patch (scalar loads)
+    const int32_t* pel; const int32_t* pnodes;          // the patch's elements (ascending, -1 padded) and their nodes [a][local element]
+    const uint2* items; const uint16_t* codes;
+    const uint2* fitems; const uint16_t* fcodes;
+    double* Pc; double* Pf;                             // partial blocks (4 doubles per slot) / partial forces (2)
+    double* data; double* F;                            // CSR values / nodal force (either may be NULL)
+    int dbg;                                            // ablation switches (FEP_PATCH_DBG), 0 in production
+};
+
+template <int NP, int NQ, bool FROM_U, bool GEO, bool PATCH = false>
 __global__ void __launch_bounds__(kBlock)
 element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                const double* __restrict__ dphi1, const double* __restrict__ dphi2, const double* __restrict__ weight,
@@ -310,24 +335,42 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                double* __restrict__ Eout, double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
                uint2* blk_counts,
                // outputs of phase 2 (kc_aos: all stored blocks of an element adjacent, see sym_block_index)
-               double* __restrict__ Kc, double* __restrict__ fe, int kc_aos) {
+               double* __restrict__ Kc, double* __restrict__ fe, int kc_aos, PatchArgs pa) {
     using C = ElemCfg<NP, NQ, GEO>;
     constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
-    constexpr int NJ = NP / 2 + 1;                   // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
-    __shared__ double d1s[NP][NPTS], d2s[NP][NPTS];
-    __shared__ double Ds[6][NPTS], Ss[3][NPTS];
-    __shared__ double2 cxy[GEO ? NP : 1][EB], cu[FROM_U ? NP : 1][EB];   // node coordinates / displacements per element
-    __shared__ double t1[GEO ? NP * NQ : 1], t2[GEO ? NP * NQ : 1], tw[GEO ? NQ : 1];
+    constexpr int NJ = C::NJ;                        // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
+    constexpr int kP12 = C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2) + (GEO ? C::kTab : 4);
+    constexpr int kLds = (PATCH && C::kPhase3 > kP12) ? C::kPhase3 : kP12;                  // phases 1-2 | phase 3, same memory
+    static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
+    __shared__ __attribute__((aligned(16))) double lds[kLds];
+    double (*d1s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds);
+    double (*d2s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + NP * NPTS);
+    double (*Ds)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + 2 * NP * NPTS);
+    double (*Ss)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + (2 * NP + 6) * NPTS);
+    double2 (*cxy)[EB] = reinterpret_cast<double2 (*)[EB]>(lds + C::kPts);                       // node coordinates per element
+    double2 (*cu)[EB] = reinterpret_cast<double2 (*)[EB]>(lds + C::kPts + (GEO ? C::kXY : 2));   // node displacements
+    double* t1 = lds + C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2);
+    double* t2 = t1 + (GEO ? NP * NQ : 1);
+    double* tw = t2 + (GEO ? NP * NQ : 1);
+    uint32_t* codes32 = reinterpret_cast<uint32_t*>(lds + C::kKl + C::kFl);              // phase 3: behind the blocks and force pairs
+    uint32_t* fcodes32 = reinterpret_cast<uint32_t*>(lds + C::kKl + C::kFl + C::kCodes);
 
     const int t = threadIdx.x;
-    const int64_t e0blk = (int64_t)blockIdx.x * EB;
+    const int64_t e0blk = (int64_t)blockIdx.x * EB;     // COO form: the workgroup's elements are e0blk .. e0blk + nel - 1
     const int64_t n_int = n_e * NQ;
-    const int nel = (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
+    // patch form: the elements are listed in pel (any ids, ascending); pdesc: 8 ints per patch (uniform address: scalar loads)
+    const int32_t* pd = PATCH ? pa.pdesc + (int64_t)blockIdx.x * 8 : nullptr;
+    const int item_off = PATCH ? pd[0] : 0, n_items = PATCH ? pd[1] : 0, code_off = PATCH ? pd[2] : 0, n_codes = PATCH ? pd[3] : 0;
+    const int fitem_off = PATCH ? pd[4] : 0, n_fitems = PATCH ? pd[5] : 0, fcode_off = PATCH ? pd[6] : 0, n_fcodes = PATCH ? pd[7] : 0;
+    const int nel = PATCH ? n_fcodes / NP : (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
 
+    __shared__ int32_t pel_s[PATCH ? EB : 1];
+    if (PATCH && t < EB) pel_s[t] = pa.pel[(int64_t)blockIdx.x * EB + t];
     if (FROM_U || GEO) {
-        for (int i = t; i < NP * EB; i += kBlock) {
-            const int a = i / EB, el = i - a * EB;
-            const int64_t nd = el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0;
+        if (t < NP * EB) {
+            const int a = t / EB, el = t - a * EB;
+            const int64_t nd = PATCH ? pa.pnodes[((int64_t)blockIdx.x * NP + a) * EB + el]
+                                     : (el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0);
             if (GEO) cxy[a][el] = *reinterpret_cast<const double2*>(xy + 2 * nd);
             if (FROM_U) cu[a][el] = *reinterpret_cast<const double2*>(U + 2 * nd);
         }
@@ -335,15 +378,16 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             for (int i = t; i < NP * NQ; i += kBlock) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
             for (int i = t; i < NQ; i += kBlock) tw[i] = wf[i];
         }
-        __syncthreads();
     }
+    if (FROM_U || GEO || PATCH) __syncthreads();
 
-    // ---- phase 1 --------------------------------------------------------------------
+    // ---- phase 1 (one pass: EB * NQ <= kBlock).  The point's operand loads are issued here, after the barrier: hoisting
+    // them (and the patch tables) in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
     int branch = 0;
-    for (int pt = t; pt < EB * NQ; pt += kBlock) {
-        const int el = pt / NQ, q = pt - el * NQ;
-        if (el >= nel) continue;
-        const int64_t k = e0blk * NQ + pt;
+    const int el1 = t / NQ, q1 = t - el1 * NQ;
+    if (t < EB * NQ && el1 < nel) {
+        const int el = el1, q = q1;
+        const int64_t k = PATCH ? (int64_t)pel_s[el] * NQ + q : e0blk * NQ + t;
         const int li = el * NQS + q;
         double w;
         double g1[NP], g2[NP];
@@ -391,15 +435,14 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     if (FROM_U) count_branches(branch, nullptr, blk_counts);
     __syncthreads();
 
-    // ---- phase 2 --------------------------------------------------------------------
-    for (int i = t; i < NP * EB; i += kBlock) {
-        const int a = i / EB, el = i - a * EB;
-        if (el >= nel) continue;
-        const int64_t e = e0blk + el;
-        double kk[NJ][4];
+    // ---- phase 2 (one pass: NP * EB <= kBlock) ----------------------------------------
+    double kk[NJ][4];
+    double f0 = 0.0, f1 = 0.0;
+    const int a = t / EB, el = t - a * EB;
+    const bool lane2 = t < NP * EB && el < nel;
+    if (lane2) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { kk[j][0] = 0.0; kk[j][1] = 0.0; kk[j][2] = 0.0; kk[j][3] = 0.0; }
-        double f0 = 0.0, f1 = 0.0;
 #pragma unroll 1
         for (int q = 0; q < NQ; ++q) {
             const int li = el * NQS + q;
@@ -421,6 +464,10 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                 kk[j][3] += r11 * b2 + r12 * b1;
             }
         }
+    }
+    if (!PATCH) {
+        if (!lane2) return;
+        const int64_t e = e0blk + el;
         if (Kc) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -431,7 +478,144 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             }
         }
         if (fe) *reinterpret_cast<double2*>(fe + ((int64_t)a * n_e + e) * 2) = make_double2(f0, f1);
+        return;
     }
+
+    // ---- phase 3 (patch route) --------------------------------------------------------
+    double2* Kl2 = reinterpret_cast<double2*>(lds);                    // stored block (idx, el) at [(idx * EB + el) * 2 + {0, 1}]
+    double2* fl2 = reinterpret_cast<double2*>(lds + C::kKl);           // force pair (a, el) at [a * EB + el]
+    const uint16_t* codes_l = reinterpret_cast<const uint16_t*>(codes32);
+    const uint16_t* fcodes_l = reinterpret_cast<const uint16_t*>(fcodes32);
+    // the lane's first items and its share of the gather codes are fetched before the barrier (independent of phase 2)
+    constexpr int IT = 4;                               // items per lane and round
+    const uint2* its = pa.items + item_off;
+    uint2 dsc[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) { const int it = u * kBlock + t; dsc[u] = (pa.data && it < n_items) ? its[it] : make_uint2(0u, 0u); }
+    constexpr int CWPT = (NP * NP * EB / 2 + kBlock) / kBlock, FWPT = (NP * EB / 2 + kBlock) / kBlock;
+    uint32_t cpre[CWPT], fpre[FWPT];
+    {   // two codes per 32-bit word (every patch's codes start at an even offset; one pad entry may be read)
+        const uint32_t* cg = reinterpret_cast<const uint32_t*>(pa.codes + code_off);
+        const uint32_t* fg = reinterpret_cast<const uint32_t*>(pa.fcodes + fcode_off);
+#pragma unroll
+        for (int r = 0; r < CWPT; ++r) { const int i = r * kBlock + t; cpre[r] = (pa.data && i < (n_codes + 1) / 2) ? cg[i] : 0u; }
+#pragma unroll
+        for (int r = 0; r < FWPT; ++r) { const int i = r * kBlock + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
+    }
+    __syncthreads();                                                   // every lane is done reading the phase-2 operands
+    if (lane2) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (NP % 2 == 0 && j == NP / 2 && a >= NP / 2) continue;
+            double2* dst = Kl2 + ((j * NP + a) * EB + el) * 2;
+            dst[0] = make_double2(kk[j][0], kk[j][1]);
+            dst[1] = make_double2(kk[j][2], kk[j][3]);
+        }
+        fl2[a * EB + el] = make_double2(f0, f1);
+    }
+#pragma unroll
+    for (int r = 0; r < CWPT; ++r) { const int i = r * kBlock + t; if (i < (n_codes + 1) / 2) codes32[i] = cpre[r]; }
+#pragma unroll
+    for (int r = 0; r < FWPT; ++r) { const int i = r * kBlock + t; if (i < (n_fcodes + 1) / 2) fcodes32[i] = fpre[r]; }
+    __syncthreads();
+    if (pa.data && !(pa.dbg & 4)) {
+        double2* data2 = reinterpret_cast<double2*>(pa.data);
+        double2* Pc2 = reinterpret_cast<double2*>(pa.Pc);
+        for (int base = 0; base < n_items; base += IT * kBlock) {
+            if (base > 0) {
+#pragma unroll
+                for (int u = 0; u < IT; ++u) { const int it = base + u * kBlock + t; dsc[u] = it < n_items ? its[it] : make_uint2(0u, 0u); }
+            }
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                if (base + u * kBlock + t >= n_items) continue;
+                const uint32_t x = dsc[u].x, y = dsc[u].y;
+                const int off = (int)(x & 8191u), cnt = (int)((x >> 13) & 63u) + 1;
+                double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+                for (int k = 0; k < cnt; ++k) {
+                    const unsigned code = codes_l[off + k];
+                    const double2* src = Kl2 + (code >> 1) * 2;
+                    const double2 r0 = src[0], r1 = src[1];
+                    const bool tr = code & 1u;
+                    a00 += r0.x; a01 += tr ? r1.x : r0.y; a10 += tr ? r0.y : r1.x; a11 += r1.y;
+                }
+                if (x >> 31) {                                         // partial: slot y of the side buffer
+                    if ((pa.dbg & 2) && a00 != 1.2345e300) continue;
+                    Pc2[2 * (int64_t)y] = make_double2(a00, a01);
+                    Pc2[2 * (int64_t)y + 1] = make_double2(a10, a11);
+                } else {                                               // finished CSR block: its two rows
+                    if ((pa.dbg & 1) && a00 != 1.2345e300) continue;
+                    const int deg = (int)((x >> 19) & 4095u);
+                    data2[y] = make_double2(a00, a01);
+                    data2[(int64_t)y + deg] = make_double2(a10, a11);
+                }
+            }
+        }
+    }
+    if (pa.F) {
+        double2* F2 = reinterpret_cast<double2*>(pa.F);
+        double2* Pf2 = reinterpret_cast<double2*>(pa.Pf);
+        for (int it = t; it < n_fitems; it += kBlock) {
+            const uint2 d = pa.fitems[fitem_off + it];
+            const int off = (int)(d.x & 8191u), cnt = (int)((d.x >> 13) & 63u) + 1;
+            double g0 = 0.0, g1 = 0.0;
+            for (int k = 0; k < cnt; ++k) { const double2 v = fl2[fcodes_l[off + k]]; g0 += v.x; g1 += v.y; }
+            if (d.x >> 31) Pf2[d.y] = make_double2(g0, g1); else F2[d.y] = make_double2(g0, g1);
+        }
+    }
+}
+
+// Second kernel of the patch route: one lane per OPEN block (a node pair on a patch boundary) adds the patches' partials
+// in ascending patch order and writes the CSR block; the workgroups behind those do the same for the open nodes' forces.
+// With counts_out the first workgroup sums the element kernel's branch counters on the side.
+__global__ void __launch_bounds__(kBlock)
+fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, int64_t n_fopen, const uint4* __restrict__ ffix,
+             const int32_t* __restrict__ plist, const double* __restrict__ Pc, const double* __restrict__ Pf,
+             double* __restrict__ data, double* __restrict__ F,
+             int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out, int dbg) {
+    const int g = counts_out != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (g < 0) { sum_block_counts(n_count_blocks, blk_counts, counts_out); return; }
+    if (g < nb_k) {
+        const int64_t i = (int64_t)g * kBlock + threadIdx.x;
+        if (i >= n_open) return;
+        const uint4 f = fix[i];
+        const int cnt = (int)(f.y >> 16), deg = (int)(f.y & 0xffffu);
+        const double2* P2 = reinterpret_cast<const double2*>(Pc);
+        double a00, a01, a10, a11;
+        if (cnt <= 2) {
+            const double2 p0 = P2[2 * (int64_t)f.z], p1 = P2[2 * (int64_t)f.z + 1];
+            a00 = 0.0 + p0.x; a01 = 0.0 + p0.y; a10 = 0.0 + p1.x; a11 = 0.0 + p1.y;
+            if (cnt == 2) {
+                const double2 q0 = P2[2 * (int64_t)f.w], q1 = P2[2 * (int64_t)f.w + 1];
+                a00 += q0.x; a01 += q0.y; a10 += q1.x; a11 += q1.y;
+            }
+        } else {
+            a00 = a01 = a10 = a11 = 0.0;
+            for (int k = 0; k < cnt; ++k) {
+                const int64_t s = plist[(int64_t)f.w + k];
+                const double2 p0 = P2[2 * s], p1 = P2[2 * s + 1];
+                a00 += p0.x; a01 += p0.y; a10 += p1.x; a11 += p1.y;
+            }
+        }
+        if ((dbg & 8) && a00 != 1.2345e300) return;
+        double2* data2 = reinterpret_cast<double2*>(data);
+        data2[f.x] = make_double2(a00, a01);
+        data2[(int64_t)f.x + deg] = make_double2(a10, a11);
+        return;
+    }
+    const int64_t i = (int64_t)(g - nb_k) * kBlock + threadIdx.x;
+    if (i >= n_fopen) return;
+    const uint4 f = ffix[i];
+    const int cnt = (int)f.y;
+    const double2* P2 = reinterpret_cast<const double2*>(Pf);
+    double g0 = 0.0, g1 = 0.0;
+    if (cnt == 2) {
+        const double2 p = P2[f.z], q = P2[f.w];
+        g0 = (0.0 + p.x) + q.x; g1 = (0.0 + p.y) + q.y;
+    } else {
+        for (int k = 0; k < cnt; ++k) { const double2 p = P2[plist[(int64_t)f.w + k]]; g0 += p.x; g1 += p.y; }
+    }
+    reinterpret_cast<double2*>(F)[f.x] = make_double2(g0, g1);
 }
 
 // ---------------------------------------------------------------------------------------

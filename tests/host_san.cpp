@@ -1,9 +1,10 @@
 // Host-only driver of fem-elastoplasticity_amd/csrc/fep_host.h for the sanitizer builds
 // (tests/test_host_sanitizers.py: g++ -fsanitize=address,undefined and -fsanitize=thread; CPU only, no HIP).
 //   host_san MESHFILE [max_segs]
-// MESHFILE: int32 n_p, n_e, n_n, then elements (n_p x n_e, C order).  Runs the symbolic phase (threaded), the COO
+// MESHFILE: int32 n_p, n_e, n_n, then elements (n_p x n_e, C order), optionally 2 x n_n doubles of coordinates.  Runs the symbolic phase (threaded), the COO
 // tiles, the P1 plans with every table option (validated against the mesh), the opt-in node plan of P2/Q1/Q2 and
 // the multigrid aggregation on the node graph; prints one summary line per plan; exit code 0 = all consistent.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -22,6 +23,8 @@ int main(int argc, char** argv) {
     const int64_t n_e = hdr[1], n_n = hdr[2];
     std::vector<int32_t> elem((size_t)n_p * n_e);
     if (std::fread(elem.data(), sizeof(int32_t), elem.size(), f) != elem.size()) return 2;
+    std::vector<double> coords(2 * (size_t)n_n);          // optional: planar coordinates x[n_n], y[n_n] behind the elements
+    const bool have_coords = std::fread(coords.data(), sizeof(double), coords.size(), f) == coords.size();
     std::fclose(f);
     const int max_segs = argc > 2 ? std::atoi(argv[2]) : 2;
     Symbolic S;
@@ -92,6 +95,34 @@ int main(int argc, char** argv) {
                         (int)((code >> 4) & 15) != ab / n_p || (int)(code & 15) != ab % n_p) rc = 1;
                 }
             }
+        }
+    }
+    // patch plans of the element route (every element type runs it; P1 with FEP_P1_PATH=coo), at the kernels' patch sizes
+    // and at odd ones, both groupings (consecutive elements / Hilbert curve through the centroids; a mesh file without
+    // coordinates: node id -> a point of a 2-D lattice stands in) and both classifications of open blocks;
+    // replayed against the symbolic phase contribution by contribution
+    {
+        std::vector<double> xy(2 * (size_t)n_n);
+        const int64_t side = (int64_t)std::ceil(std::sqrt((double)n_n));
+        for (int64_t n = 0; n < n_n; ++n) { xy[n] = (double)(n % side); xy[n_n + n] = (double)(n / side); }
+        if (have_coords) xy = coords;
+        const int ebs_np[][4] = {{3, 64, 7, 1}, {6, 32, 28, 5}, {4, 64, 9, 2}, {8, 28, 24, 3}, {15, 16, 4, 1}};
+        for (const auto& row : ebs_np) {
+            if (row[0] != n_p) continue;
+            for (int k = 1; k < 4; ++k)
+                for (int variant = 0; variant < 3; ++variant) {
+                    PatchOptions opt;
+                    opt.order = variant == 0 ? 0 : 1;
+                    opt.open_rows = variant == 2;
+                    PatchPlan P;
+                    r = build_patch_plan(S, n_p, n_e, n_n, elem.data(), xy.data(), row[k], opt, P);
+                    const int bad = r == FEP_OK ? validate_patch_plan(P, S, n_p, n_e, n_n, elem.data()) : -1;
+                    std::printf("patch plan eb %d order %d open_rows %d: rc %d ok %d check %d patches %lld items %zu (<= %d per patch) open blocks %lld "
+                                "partials %lld (%.3f per element) open nodes %lld\n", row[k], opt.order, (int)opt.open_rows, r, (int)P.ok, bad,
+                                (long long)P.n_patch, P.items.size(), P.max_items, (long long)P.n_open, (long long)P.n_part,
+                                (double)P.n_part / (double)n_e, (long long)P.n_fopen);
+                    if (r != FEP_OK || bad || !P.ok) rc = 1;
+                }
         }
     }
     // multigrid aggregation on the node graph

@@ -149,12 +149,14 @@ def test_elastic_setup_vs_reference_golden(fep, t):
 
 
 # ---- a1..a5 ---------------------------------------------------------------------------
-@pytest.fixture(params=['node', 'node2k', 'node_unpacked', 'node_list', 'node_direct', 'coo'])
+@pytest.fixture(params=['node', 'node2k', 'node_unpacked', 'node_list', 'node_direct', 'coo', 'coo_kc'])
 def p1_route(request, monkeypatch):
     """P1 routes: the node-centric fast path (default: one fused kernel per non-accepting step, two kernels otherwise;
-    'node2k' = always two kernels; the other node_* names switch off one table compression each) and the generic COO
-    route."""
-    monkeypatch.setenv('FEP_P1_PATH', request.param)
+    'node2k' = always two kernels; the other node_* names switch off one table compression each) and the generic element
+    route ('coo': its default patch form, 'coo_kc': with the K_e round trip through HBM)."""
+    monkeypatch.setenv('FEP_P1_PATH', 'coo' if request.param == 'coo_kc' else request.param)
+    if request.param == 'coo_kc':
+        monkeypatch.setenv('FEP_GEN_PATH', 'coo')
     return request.param
 
 
@@ -237,6 +239,7 @@ def test_reduce_kernel_forms_are_bitwise_equal(fep, monkeypatch, t, n):
     x, y = mesh['coordinates']
     U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
     res = []
+    monkeypatch.setenv('FEP_GEN_PATH', 'coo')
     for env in ({}, {'FEP_CSR_UNPACKED': '1', 'FEP_CSR_GATHERS': '2'}, {'FEP_CSR_UNPACKED': '1', 'FEP_CSR_GATHERS': '8'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -301,11 +304,85 @@ def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
     ctx.close()
 
 
-@pytest.fixture(params=['node', 'coo'])
+@pytest.fixture(params=['node', 'coo', 'patch'])
 def gen_route(request, monkeypatch):
-    """P2 / Q1 / Q2 have two routes: the COO route (default, also what P4 uses) and the opt-in node route."""
+    """P2 / Q1 / Q2 have three routes: the element route in its patch form (default, also what P4 uses: K_e stays in
+    LDS), the same with the K_e round trip through HBM ('coo') and the opt-in node route."""
     monkeypatch.setenv('FEP_GEN_PATH', request.param)
+    monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
     return request.param
+
+
+def _patch_cases(fep):
+    rng = np.random.default_rng(77)
+    out = {}
+    for t, n in (('P2', 37), ('Q1', 45), ('Q2', 23), ('P1', 52)):
+        m = fep.square_mesh(n, t, 10)
+        out[f'square_{t}'] = (m['elements'], m['coordinates'])
+    g = load_golden('tsx')
+    out['tsx_P1'] = (g['elem'], g['coord'])
+    out['tsx_P2'] = (g['p2_elem'], g['p2_coord'])
+    out['tsx_P4'] = (g['p4_elem'], g['p4_coord'])
+    m = fep.square_mesh(14, 'P2', 10)                                       # randomly numbered elements and nodes: patches
+    perm = rng.permutation(m['coordinates'].shape[1])                       # without locality, many partials per block
+    inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+    out['shuffled_P2'] = (inv[m['elements'][:, rng.permutation(m['elements'].shape[1])]], m['coordinates'][:, perm])
+    m = fep.square_mesh(12, 'Q2', 10)                                       # two nodes of no element
+    co = m['coordinates']
+    out['orphans_Q2'] = (np.where(m['elements'] >= 50, m['elements'] + 1, m['elements']),
+                         np.concatenate([co[:, :50], [[3.3], [4.4]], co[:, 50:], [[20.0], [20.0]]], axis=1))
+    m = fep.square_mesh(1, 'P2', 10)                                        # a single patch: nothing open
+    out['one_cell_P2'] = (m['elements'], m['coordinates'])
+    return out
+
+
+@pytest.mark.parametrize('name', ['square_P2', 'square_Q1', 'square_Q2', 'square_P1', 'tsx_P1', 'tsx_P2', 'tsx_P4', 'shuffled_P2',
+                                  'orphans_Q2', 'one_cell_P2'])
+def test_patch_route_against_the_coo_route(fep, monkeypatch, name):
+    """Element route, patch form (K_e blocks summed inside the workgroup's LDS, partials only for node pairs on a patch
+    boundary) against the COO form (every K_e block through HBM, one flat sum per CSR block): the point outputs are the same
+    kernel code (bit-identical), K and F differ by the association of the sums only (<= 1e-13 of the array maximum, every
+    row of K <= 1e-12 of its own maximum); step and assemble_tangent agree bit for bit on each route; run-to-run bitwise
+    reproducible.  The plan is replayed against the symbolic phase (FEP_VALIDATE_PLAN)."""
+    elem, coord = _patch_cases(fep)[name]
+    n_p = elem.shape[0]
+    t = {3: 'P1', 6: 'P2', 4: 'Q1', 8: 'Q2', 15: 'P4'}[n_p]
+    n = elem.shape[1] * NQ[t]
+    rng = np.random.default_rng(5)
+    x, y = coord
+    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    U += rng.normal(0, 3e-6, size=U.shape)
+    Ep = rng.normal(0, 5e-6, size=(4, n))
+    monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
+    monkeypatch.setenv('FEP_P1_PATH', 'coo')
+    res = {}
+    for route in ('coo', 'patch'):
+        monkeypatch.setenv('FEP_GEN_PATH', route)
+        ctx = fep.MeshContext(elem, coord)
+        ctx.set_materials(*dp_materials(n))
+        F_poison = ctx.step(1e3 * U, None, want=('K', 'F'))                   # other values in the scratch buffers
+        r = ctx.step(U, Ep.copy(), want=('E', 's', 'ds', 'ind_p', 'K', 'F'))
+        r2 = ctx.step(U, Ep.copy(), want=('K', 'F'))                          # K,F-only call: same values
+        assert np.array_equal(r2['K'].data, r['K'].data) and np.array_equal(r2['F'], r['F'])
+        ep = Ep.copy()
+        acc = ctx.step(U, ep, apply_plastic_strain=True, want=('K', 'F'))
+        assert np.array_equal(acc['K'].data, r['K'].data) and np.array_equal(acc['F'], r['F'])
+        K2, F2 = ctx.assemble(r['ds'], r['s'])
+        assert np.array_equal(K2.data, r['K'].data) and np.array_equal(F2, r['F'])
+        _, F3 = ctx.assemble(None, r['s'])
+        K3, _ = ctx.assemble(r['ds'], None)
+        assert np.array_equal(F3, r['F']) and np.array_equal(K3.data, r['K'].data)
+        res[route] = (r, ep)
+        ctx.close()
+    a, b = res['coo'][0], res['patch'][0]
+    assert (a['n_smooth'] > 0 or n < 100) and (a['n_smooth'], a['n_apex']) == (b['n_smooth'], b['n_apex'])
+    for k in ('E', 's', 'ds', 'ind_p'):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(res['coo'][1], res['patch'][1])
+    assert relerr(b['K'].data, a['K'].data) <= 1e-13 and relerr(b['F'], a['F']) <= 1e-13
+    assert relerr_rows(b['K'], a['K']) <= 1e-12
+    if name == 'orphans_Q2':
+        assert b['F'][2 * 50] == 0 and b['F'][2 * 50 + 1] == 0 and b['F'][-1] == 0 and b['F'][-2] == 0
 
 
 @pytest.mark.parametrize('t,N', [('P2', 24), ('Q1', 40), ('Q2', 20)])
