@@ -39,6 +39,8 @@ struct fep_ctx {
     uint2 *pt_items = nullptr, *pt_fitems = nullptr;
     uint16_t *pt_codes = nullptr, *pt_fcodes = nullptr;
     uint4 *pt_fix = nullptr, *pt_ffix = nullptr;
+    uint2* pt_fixT = nullptr;
+    int64_t n_patch = 0;
     double *Pc = nullptr, *Pf = nullptr;                // partial blocks / forces of the open items (scratch, rewritten by every step)
     bool elem_geo = true;                               // element_kernel: geometry from coordinates instead of the dphi arrays
     MatU matu{};                                        // homogeneous-material fast path (arrays not read)
@@ -330,7 +332,7 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
                         c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tdesc, c->tstart,
                         c->wg_nlist, c->wg_nrng, c->el_nodes, c->slot_counts, c->pkc, c->pt_desc, c->pt_plist, c->pt_items,
-                        c->pt_fitems, c->pt_codes, c->pt_fcodes, c->pt_fix, c->pt_ffix, c->Pc, c->Pf, c->pt_pel, c->pt_pnodes};
+                        c->pt_fitems, c->pt_codes, c->pt_fcodes, c->pt_fix, c->pt_ffix, c->Pc, c->Pf, c->pt_pel, c->pt_pnodes, c->pt_fixT};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -495,7 +497,11 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         // measured on MI355X (1 M elements, element kernel alone): recomputed geometry wins for Q1 (0.204 vs 0.218 ms) and
         // Q2 (0.344 vs 0.391 ms with 24 instead of 28 elements per workgroup, so that three workgroups still fit a CU) and
         // loses for P2 (0.50 vs 0.47 ms at 28 / 32 elements per workgroup)
-        c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : (elem_type == FEP_Q1 || elem_type == FEP_Q2);
+        // round 3, patch form of the element route: recomputed geometry wins for P2 as well (same session, 1 M elements:
+        // 0.754 vs 0.783 ms on a fast box, 0.888 vs 0.936 on a slow one); the COO form keeps the streamed dphi arrays for P2
+        const char* gpth = std::getenv("FEP_GEN_PATH");
+        const bool coo_form = gpth && std::strcmp(gpth, "coo") == 0;
+        c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : (elem_type == FEP_Q1 || elem_type == FEP_Q2 || (elem_type == FEP_P2 && !coo_form));
     }
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
@@ -515,15 +521,22 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         if (!(gp && std::strcmp(gp, "coo") == 0)) {
             fep_host::PatchPlan P;
             fep_host::PatchOptions popt;
-            if (const char* po = std::getenv("FEP_PATCH_ORDER")) popt.order = std::strcmp(po, "consecutive") == 0 ? 0 : 1;
-            if (const char* pr = std::getenv("FEP_PATCH_OPEN")) popt.open_rows = std::strcmp(pr, "rows") == 0;
+            if (const char* po = std::getenv("FEP_PATCH_ORDER"))
+                popt.order = std::strcmp(po, "consecutive") == 0 ? 0 : std::strcmp(po, "hilbert") == 0 ? 1 : 2;
+            if (const char* pr = std::getenv("FEP_PATCH_RUNS")) popt.runs = std::max(1, std::atoi(pr));
+            {   // elements per full 128-byte line of a point array row: 16 / gcd(16, n_q)
+                int g = 16, b = n_q;
+                while (b) { const int t = g % b; g = b; b = t; }
+                popt.align = 16 / g;
+                if (const char* pa = std::getenv("FEP_PATCH_ALIGN")) popt.align = std::max(1, std::atoi(pa));
+            }
             CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
             if (r == FEP_OK && P.ok && std::getenv("FEP_VALIDATE_PLAN")) {
                 const int bad = fep_host::validate_patch_plan(P, S, n_p, n_e, n_n, elements_h);
                 if (bad) { std::fprintf(stderr, "[fep] patch plan fails check %d\n", bad); r = FEP_EINVAL; }
             }
             if (r == FEP_OK && P.ok) {
-                c->patch = true; c->patch_eb = P.eb; c->n_open = P.n_open; c->n_fopen = P.n_fopen;
+                c->patch = true; c->patch_eb = P.eb; c->n_open = P.n_open; c->n_fopen = P.n_fopen; c->n_patch = P.n_patch;
                 if (const char* db = std::getenv("FEP_PATCH_DBG")) c->patch_dbg = std::atoi(db);
                 CK(upload(&c->pt_desc, P.pdesc.data(), (int64_t)P.pdesc.size()));
                 CK(upload(&c->pt_pel, P.pel.data(), (int64_t)P.pel.size()));
@@ -533,6 +546,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 CK(upload(&c->pt_fitems, (const uint2*)P.fitems.data(), (int64_t)P.fitems.size()));
                 CK(upload(&c->pt_fcodes, P.fcodes.data(), (int64_t)P.fcodes.size()));
                 CK(upload(&c->pt_fix, (const uint4*)P.fix.data(), (int64_t)P.fix.size()));
+                CK(upload(&c->pt_fixT, (const uint2*)P.fixT.data(), (int64_t)P.fixT.size()));
                 CK(upload(&c->pt_ffix, (const uint4*)P.ffix.data(), (int64_t)P.ffix.size()));
                 CK(upload(&c->pt_plist, P.plist.data(), (int64_t)P.plist.size()));
                 CK(dmalloc(&c->Pc, 4 * P.n_part));
@@ -545,7 +559,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                                  (long long)P.n_fopen);
             }
         }
-        c->n_count_blocks = (int)grid_for(n_e, elem_eb);
+        c->n_count_blocks = c->patch ? (int)c->n_patch : (int)grid_for(n_e, elem_eb);
     }
     if (!c->patch) {
         CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
@@ -694,7 +708,8 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
 #define ELEM_LAUNCH(GEO, PATCH)                                                                                          \
     do {                                                                                                                 \
         if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO>::EB) return FEP_ESTATE;                             \
-        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH>), dim3(grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)), \
+        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH>),                                                \
+                           dim3(PATCH ? (unsigned)c->n_patch : grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)),                \
                            dim3(kBlock), (size_t)c->lds_pad, st, c->n_e,                                                \
                            c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,   \
                            c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts,                       \
@@ -761,7 +776,7 @@ static int launch_fixup(fep_ctx* c, hipStream_t st, double* k_data, double* f_ou
     const unsigned nb_f = f_out ? grid_for(c->n_fopen, kBlock) : 0u;
     const unsigned grid = nb_k + nb_f + (counts_d ? 1u : 0u);
     if (grid > 0) {
-        hipLaunchKernelGGL(fixup_kernel, dim3(grid), dim3(kBlock), 0, st, (int)nb_k, c->n_open, c->pt_fix, c->n_fopen, c->pt_ffix,
+        hipLaunchKernelGGL(fixup_kernel, dim3(grid), dim3(kBlock), 0, st, (int)nb_k, c->n_open, c->pt_fix, c->pt_fixT, c->n_fopen, c->pt_ffix,
                            c->pt_plist, c->Pc, c->Pf, k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d, c->patch_dbg);
         HIP_TRY(hipGetLastError());
         if (counts_done) *counts_done = counts_d != nullptr;

@@ -667,8 +667,9 @@ inline void build_gn_plan(const Symbolic& S, int n_p, int n_q, int64_t n_e, GnPl
 //   open item    the block also gets contributions from other patches (node pairs on a patch-boundary edge) -> the sum
 //                is a PARTIAL, written to slot `y` of a side buffer (32 bytes per slot, a patch's slots consecutive);
 //                fixup_kernel adds a block's partials in ascending patch order and writes the CSR block.
-//   (`open_rows`: every block whose ROW NODE has elements in several patches is open, so that whole CSR rows are
-//    written by one kernel — more partials, no partially written rows.)
+//                K is symmetric block by block (every stored K_e block serves (a, b) and, transposed, (b, a); same
+//                summation order), so only the UPPER open blocks (row node <= column node) have items and partials:
+//                fixup_kernel writes the block and its transposed mirror.
 // Forces: the same with one item per node of the patch (closed: all incident elements inside the patch).
 // Deterministic (fixed order, no atomics); the association differs from the flat element order of the COO route
 // ((a+b+c) + (d+e+f) instead of a+b+c+d+e+f for a vertex on a patch boundary), so the two routes agree to rounding only.
@@ -679,16 +680,20 @@ inline void build_gn_plan(const Symbolic& S, int n_p, int n_q, int64_t n_e, GnPl
 //           y: closed: position of the block's first row in double2 units (2*nptr[n] + slot); open: partial slot
 //   codes   uint16 (position of the stored block in LDS = idx*eb + local element) << 1 | transposed
 //   fitems  x: code offset:13 | (count-1):6 | open << 31;  y: node | force partial slot;   fcodes  a*eb + local element
-//   fix     per open block: x = position (as items.y), y = degree | count << 16, z = first partial slot,
+//   fix     per upper open block: x = position (as items.y), y = degree | count << 16, z = first partial slot,
 //           w = second partial slot (count <= 2) or offset into plist (count > 2: `count` slots, ascending patch)
+//   fixT    its mirror: x = position of the transposed block (0xffffffff: diagonal block, no mirror), y = degree of ITS row node
 //   ffix    per open node:  x = node, y = count, z / w as above
 // ---------------------------------------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 constexpr int kPatchDescInts = 8;
 
 struct PatchOptions {
-    int order = 1;                                      // 0: consecutive elements, 1: Hilbert curve through the centroids
-    bool open_rows = false;
+    int order = 2;                                      // 0: consecutive elements, 1: Hilbert curve through the centroids,
+                                                        // 2: up to `runs` runs of consecutive elements, each the neighbours of the one before
+    int runs = 2;
+    int align = 1;                                      // runs start at multiples of `align` elements where they can (full 128-byte
+                                                        // lines of the point arrays: 16 / gcd(16, n_q) elements)
 };
 
 struct PatchPlan {
@@ -699,6 +704,7 @@ struct PatchPlan {
     std::vector<U2> items, fitems;
     std::vector<uint16_t> codes, fcodes;
     std::vector<U4> fix, ffix;
+    std::vector<U2> fixT;
 };
 
 // where element_kernel keeps the block (a, b) of K_e (same function as fep::sym_block_index, block-major numbering)
@@ -723,9 +729,72 @@ inline uint32_t hilbert_d(uint32_t x, uint32_t y) {
     return d;
 }
 
+// Patches of up to `runs` RUNS of consecutive element ids (what keeps the point arrays' accesses in long contiguous
+// pieces): the first run starts at the lowest unassigned element; every further one is the longest run of consecutive,
+// still unassigned ids among the elements that share a node with the run before (on a row-numbered mesh: the same cells
+// one row up), so that a patch is `runs` rows high instead of one — its perimeter, hence what it exchanges with its
+// neighbours, shrinks accordingly.  A patch that stays short is topped up from the lowest unassigned ids.
+inline void patch_runs(const Symbolic& S, int n_p, int64_t n_e, const int32_t* elem, int eb, int runs, int align,
+                       std::vector<int32_t>& pel, std::vector<int32_t>& patch_of) {
+    align = std::max(1, align);
+    runs = std::max(1, std::min(runs, eb));
+    pel.clear();
+    patch_of.assign((size_t)n_e, -1);
+    std::vector<int32_t> cur, nbrs;
+    int64_t cursor = 0;
+    int32_t p = 0;
+    while (true) {
+        while (cursor < n_e && patch_of[cursor] >= 0) ++cursor;
+        if (cursor >= n_e) break;
+        cur.clear();
+        int64_t start = cursor;
+        for (int r = 0; r < runs && (int)cur.size() < eb; ++r) {
+            const int budget = (eb - (int)cur.size() + (runs - r) - 1) / (runs - r);     // an even share of what is left
+            const size_t run0 = cur.size();
+            for (int64_t e = start; e < n_e && patch_of[e] < 0 && (int)(cur.size() - run0) < budget; ++e) { cur.push_back((int32_t)e); patch_of[e] = p; }
+            if (r + 1 == runs || (int)cur.size() >= eb) break;
+            nbrs.clear();
+            for (size_t i = run0; i < cur.size(); ++i)
+                for (int a = 0; a < n_p; ++a) {
+                    const int32_t nd = elem[(int64_t)a * n_e + cur[i]];
+                    for (int32_t t = S.iptr[nd]; t < S.iptr[nd + 1]; ++t) {
+                        const int32_t e2 = (int32_t)((int64_t)S.ilist[t] % n_e);
+                        if (patch_of[e2] < 0) nbrs.push_back(e2);
+                    }
+                }
+            std::sort(nbrs.begin(), nbrs.end());
+            nbrs.erase(std::unique(nbrs.begin(), nbrs.end()), nbrs.end());
+            size_t best = 0, best_len = 0;
+            for (size_t i = 0; i < nbrs.size();) {
+                size_t j = i + 1;
+                while (j < nbrs.size() && nbrs[j] == nbrs[j - 1] + 1) ++j;
+                if (j - i > best_len) { best_len = j - i; best = i; }
+                i = j;
+            }
+            if (best_len < 2) break;
+            start = nbrs[best];
+            if (align > 1 && start % align) {           // a start on a line boundary of the point arrays: down if those ids are free, else up
+                const int64_t lo = start - start % align;
+                bool free_lo = true;
+                for (int64_t e = lo; e < start && free_lo; ++e) free_lo = patch_of[e] < 0;
+                if (free_lo) start = lo;
+                else if (lo + align < (int64_t)nbrs[best] + (int64_t)best_len) start = lo + align;
+            }
+        }
+        for (int64_t e = cursor; e < n_e && (int)cur.size() < eb; ++e)                   // top up
+            if (patch_of[e] < 0) { cur.push_back((int32_t)e); patch_of[e] = p; }
+        std::sort(cur.begin(), cur.end());
+        pel.insert(pel.end(), cur.begin(), cur.end());
+        pel.resize((size_t)(p + 1) * eb, -1);
+        ++p;
+    }
+}
+
 // pel / patch_of for the chosen grouping (coords: planar x[n_n], y[n_n]; may be NULL -> consecutive elements)
-inline void patch_grouping(int n_p, int64_t n_e, int64_t n_n, const int32_t* elem, const double* coords, int eb, int order,
-                           std::vector<int32_t>& pel, std::vector<int32_t>& patch_of) {
+inline void patch_grouping(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n, const int32_t* elem, const double* coords, int eb,
+                           const PatchOptions& opt, std::vector<int32_t>& pel, std::vector<int32_t>& patch_of) {
+    const int order = opt.order;
+    if (order == 2 && n_e > eb) { patch_runs(S, n_p, n_e, elem, eb, opt.runs, opt.align, pel, patch_of); return; }
     const int64_t n_patch = (n_e + eb - 1) / eb;
     pel.assign((size_t)(n_patch * eb), -1);
     patch_of.resize((size_t)n_e);
@@ -764,10 +833,10 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
     const int nj = n_p / 2 + 1;
     if (eb < 1 || (int64_t)n_p * n_p * eb > 8192 || (int64_t)nj * n_p * eb >= 32768) return FEP_OK;       // field widths: plan not usable
     const int64_t n_blk = (int64_t)S.ncol.size();
-    const int64_t n_patch = (n_e + eb - 1) / eb;
-    P.n_patch = n_patch;
     std::vector<int32_t> patch_of;
-    patch_grouping(n_p, n_e, n_n, elem, coords, eb, opt.order, P.pel, patch_of);
+    patch_grouping(S, n_p, n_e, n_n, elem, coords, eb, opt, P.pel, patch_of);
+    const int64_t n_patch = (int64_t)P.pel.size() / eb;
+    P.n_patch = n_patch;
     P.pnodes.assign((size_t)(n_patch * n_p * eb), 0);
     parallel_chunks(n_patch, [&](int64_t lo, int64_t hi, int) {
         for (int64_t p = lo; p < hi; ++p)
@@ -801,18 +870,27 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
     });
     if (bad.load()) return FEP_OK;
     // open blocks / nodes: index, table entries, plist offsets
-    auto is_open = [&](int64_t n, int32_t b) { return opt.open_rows ? npn[n] >= 2 : npb[b] >= 2; };
+    // open_idx: -1 closed, -2 lower open block (row node > column node: written by its mirror's fix-up lane), else index into fix
     std::vector<int32_t> open_idx((size_t)n_blk, -1), fopen_idx((size_t)n_n, -1);
     int64_t n_plist = 0;
     for (int64_t n = 0; n < n_n; ++n) {
         const uint32_t deg = (uint32_t)(S.nptr[n + 1] - S.nptr[n]);
         if (deg > 4095) return FEP_OK;
         for (int32_t b = S.nptr[n]; b < S.nptr[n + 1]; ++b) {
-            if (!is_open(n, b)) continue;
+            if (npb[b] < 2) continue;
+            const int64_t m = S.ncol[b];
+            if (m < n) { open_idx[b] = -2; continue; }
             open_idx[b] = (int32_t)P.fix.size();
             U4 f{(uint32_t)(2 * (int64_t)S.nptr[n] + (b - S.nptr[n])), deg | ((uint32_t)npb[b] << 16), 0u, 0u};
             if (npb[b] > 2) { f.w = (uint32_t)n_plist; n_plist += npb[b]; }
             P.fix.push_back(f);
+            U2 ft{0xffffffffu, 0u};
+            if (m != n) {                                                    // the mirror block (m, n)
+                const int32_t* row = S.ncol.data() + S.nptr[m];
+                const int64_t slot = std::lower_bound(row, S.ncol.data() + S.nptr[m + 1], (int32_t)n) - row;
+                ft = U2{(uint32_t)(2 * (int64_t)S.nptr[m] + slot), (uint32_t)(S.nptr[m + 1] - S.nptr[m])};
+            }
+            P.fixT.push_back(ft);
         }
         if (npn[n] >= 2) {
             fopen_idx[n] = (int32_t)P.ffix.size();
@@ -875,7 +953,8 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
                 if (cnt > 64) { O.fail = 1; break; }
                 const bool all_here = (int32_t)cnt == S.segptr[b + 1] - S.segptr[b];
                 if ((npb[b] < 2) != all_here) { O.fail = 2; break; }
-                if (open_idx[b] < 0) {
+                if (open_idx[b] == -2) { i = j; continue; }                 // lower open block: its mirror carries the partial
+                if (open_idx[b] == -1) {
                     const uint32_t deg = S.meta[b] >> 16, slot = S.meta[b] & 0x7fffu;
                     O.items.push_back(U2{(uint32_t)(O.codes.size() - code0) | ((cnt - 1) << 13) | (deg << 19),
                                          (uint32_t)(2 * (int64_t)(b - (int32_t)slot) + slot)});
@@ -999,8 +1078,8 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
     if (!P.ok) return 0;
     const int eb = P.eb, nj = n_p / 2 + 1;
     const int64_t n_blk = (int64_t)S.ncol.size();
-    if ((int64_t)P.pdesc.size() != P.n_patch * kPatchDescInts || P.n_patch != (n_e + eb - 1) / eb) return 1;
-    if ((int64_t)P.pel.size() != P.n_patch * eb || (int64_t)P.pnodes.size() != P.n_patch * n_p * eb) return 1;
+    if ((int64_t)P.pdesc.size() != P.n_patch * kPatchDescInts || P.n_patch < (n_e + eb - 1) / eb) return 1;
+    if ((int64_t)P.pel.size() != P.n_patch * eb || (int64_t)P.pnodes.size() != P.n_patch * n_p * eb || P.fixT.size() != P.fix.size()) return 1;
     {
         std::vector<uint8_t> owned((size_t)n_e, 0);
         for (int64_t p = 0; p < P.n_patch; ++p)
@@ -1047,7 +1126,7 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
         while (nel < eb && pe[nel] >= 0) ++nel;
         if (d[0] < 0 || d[0] + (int64_t)d[1] > (int64_t)P.items.size() || d[2] < 0 || d[2] + (int64_t)d[3] + 8 > (int64_t)P.codes.size()) return 3;
         if (d[4] < 0 || d[4] + (int64_t)d[5] > (int64_t)P.fitems.size() || d[6] < 0 || d[6] + (int64_t)d[7] + 8 > (int64_t)P.fcodes.size()) return 3;
-        if (d[3] != n_p * n_p * nel || d[7] != n_p * nel || d[1] > P.max_items || d[5] > P.max_fitems || (d[2] & 1) || (d[6] & 1)) return 4;
+        if (nel < 1 || d[3] > n_p * n_p * nel || d[7] != n_p * nel || d[1] > P.max_items || d[5] > P.max_fitems || (d[2] & 1) || (d[6] & 1)) return 4;
         std::vector<int32_t> seq;
         for (int32_t i = 0; i < d[1]; ++i) {
             const U2 it = P.items[(size_t)d[0] + i];
@@ -1108,7 +1187,7 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
             }
         }
     }
-    if (total != (int64_t)S.perm.size() || ftotal != (int64_t)S.ilist.size()) return 19;
+    if (ftotal != (int64_t)S.ilist.size()) return 19;
     for (uint8_t v : part_seen) if (!v) return 20;
     for (uint8_t v : fpart_seen) if (!v) return 20;
     std::vector<uint8_t> slot_used((size_t)P.n_part, 0), fslot_used((size_t)P.n_fpart, 0);
@@ -1138,7 +1217,21 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
             all.insert(all.end(), part_seq[(size_t)s].begin(), part_seq[(size_t)s].end());
         }
         if (!same_set(all, S.perm.data() + S.segptr[b], (size_t)(S.segptr[b + 1] - S.segptr[b]))) return 25;
+        // the mirror block: same elements, (a, b) swapped
+        const U2 ft = P.fixT[(size_t)(&f - P.fix.data())];
+        const int64_t m = S.ncol[b];
+        if (m == n) { if (ft.x != 0xffffffffu) return 39; continue; }
+        if (m < n) return 39;                                                // only upper blocks have entries
+        const int64_t slot_t = (int64_t)ft.x - 2 * (int64_t)S.nptr[m];
+        if (slot_t < 0 || slot_t >= S.nptr[m + 1] - S.nptr[m] || (int64_t)ft.y != S.nptr[m + 1] - S.nptr[m]) return 40;
+        const int64_t bt = S.nptr[m] + slot_t;
+        if (S.ncol[bt] != n || blk_seen[bt]) return 41;
+        blk_seen[bt] = 1;
+        for (int32_t& v : all) { const int64_t ab = v / n_e, e = v % n_e; v = (int32_t)(((ab % n_p) * n_p + ab / n_p) * n_e + e); }
+        if (!same_set(all, S.perm.data() + S.segptr[bt], (size_t)(S.segptr[bt + 1] - S.segptr[bt]))) return 42;
+        total += (int64_t)all.size();
     }
+    if (total != (int64_t)S.perm.size()) return 19;
     for (const U4& f : P.ffix) {
         const int cnt = (int)f.y;
         if (cnt < 2 || !slots_of(f, cnt, sl)) return 27;

@@ -16,6 +16,11 @@ namespace fep {
 
 constexpr int kBlock = 256;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding global stores
+// (s_waitcnt vmcnt(0)): behind a phase that has just issued its output stores that wait is a full store round trip on
+// the workgroup's critical path.  Use where the phases exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------
 // Per-point Drucker-Prager return map (DP:663-755).
 //   e[3]  strain (11,22,gamma12);  z[4] initial strain (TSX e0, zeros for DP);  p[4] previous
@@ -98,14 +103,14 @@ __device__ __forceinline__ void count_branches(int branch, unsigned long long* c
     if (counts == nullptr && blk_counts == nullptr) return;       // uniform
     __shared__ unsigned int sc[2];
     if (threadIdx.x == 0) { sc[0] = 0u; sc[1] = 0u; }
-    __syncthreads();
+    lds_barrier();                                                // (LDS only: the callers' point outputs are still on their way)
     const unsigned long long ms = __ballot(branch == 1);
     const unsigned long long ma = __ballot(branch == 2);
     if ((threadIdx.x & 63) == 0) {
         if (ms) atomicAdd(&sc[0], (unsigned int)__popcll(ms));
         if (ma) atomicAdd(&sc[1], (unsigned int)__popcll(ma));
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         if (blk_counts) {
             blk_counts[blockIdx.x] = make_uint2(sc[0], sc[1]);
@@ -124,12 +129,14 @@ __device__ __forceinline__ void sum_block_counts(int n_blocks, const uint2* __re
     __shared__ unsigned long long part[2][16];
     unsigned long long a = 0, b = 0;
     const int nt = blockDim.x;
-    for (int base = threadIdx.x; base < n_blocks; base += 4 * nt) {
-        uint2 v[4];
+    constexpr int UN = 8;           // loads in flight per lane: the loop is a chain of memory round trips (31 of them with 4 at
+                                    // 31 k workgroups and 256 lanes: ~50 us, the floor of the kernel that hosts this sum)
+    for (int base = threadIdx.x; base < n_blocks; base += UN * nt) {
+        uint2 v[UN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (base + j * nt < n_blocks) ? blk_counts[base + j * nt] : make_uint2(0u, 0u);
+        for (int j = 0; j < UN; ++j) v[j] = (base + j * nt < n_blocks) ? blk_counts[base + j * nt] : make_uint2(0u, 0u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a += v[j].x; b += v[j].y; }
+        for (int j = 0; j < UN; ++j) { a += v[j].x; b += v[j].y; }
     }
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; }
@@ -433,7 +440,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         Ss[0][li] = w * s[0]; Ss[1][li] = w * s[1]; Ss[2][li] = w * s[2];        // DP:1058
     }
     if (FROM_U) count_branches(branch, nullptr, blk_counts);
-    __syncthreads();
+    if (pa.dbg & 64) __syncthreads(); else lds_barrier();              // (the point outputs' stores drain behind phase 2)
 
     // ---- phase 2 (one pass: NP * EB <= kBlock) ----------------------------------------
     double kk[NJ][4];
@@ -502,7 +509,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 #pragma unroll
         for (int r = 0; r < FWPT; ++r) { const int i = r * kBlock + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
     }
-    __syncthreads();                                                   // every lane is done reading the phase-2 operands
+    if (pa.dbg & 64) __syncthreads(); else lds_barrier();              // every lane is done reading the phase-2 operands
     if (lane2) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -517,7 +524,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     for (int r = 0; r < CWPT; ++r) { const int i = r * kBlock + t; if (i < (n_codes + 1) / 2) codes32[i] = cpre[r]; }
 #pragma unroll
     for (int r = 0; r < FWPT; ++r) { const int i = r * kBlock + t; if (i < (n_fcodes + 1) / 2) fcodes32[i] = fpre[r]; }
-    __syncthreads();
+    if (pa.dbg & 64) __syncthreads(); else lds_barrier();
     if (pa.data && !(pa.dbg & 4)) {
         double2* data2 = reinterpret_cast<double2*>(pa.data);
         double2* Pc2 = reinterpret_cast<double2*>(pa.Pc);
@@ -565,11 +572,13 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     }
 }
 
-// Second kernel of the patch route: one lane per OPEN block (a node pair on a patch boundary) adds the patches' partials
-// in ascending patch order and writes the CSR block; the workgroups behind those do the same for the open nodes' forces.
+// Second kernel of the patch route: one lane per UPPER open block (a node pair on a patch boundary, row node <= column
+// node) adds the patches' partials in ascending patch order and writes the CSR block and its transposed mirror; the
+// workgroups behind those do the same for the open nodes' forces.
 // With counts_out the first workgroup sums the element kernel's branch counters on the side.
 __global__ void __launch_bounds__(kBlock)
-fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, int64_t n_fopen, const uint4* __restrict__ ffix,
+fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, const uint2* __restrict__ fixT,
+             int64_t n_fopen, const uint4* __restrict__ ffix,
              const int32_t* __restrict__ plist, const double* __restrict__ Pc, const double* __restrict__ Pf,
              double* __restrict__ data, double* __restrict__ F,
              int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out, int dbg) {
@@ -582,7 +591,8 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, int64_t n_
         const int cnt = (int)(f.y >> 16), deg = (int)(f.y & 0xffffu);
         const double2* P2 = reinterpret_cast<const double2*>(Pc);
         double a00, a01, a10, a11;
-        if (cnt <= 2) {
+        if (dbg & 32) { a00 = (double)f.z; a01 = (double)f.w; a10 = 1.0; a11 = 2.0; }
+        else if (cnt <= 2) {
             const double2 p0 = P2[2 * (int64_t)f.z], p1 = P2[2 * (int64_t)f.z + 1];
             a00 = 0.0 + p0.x; a01 = 0.0 + p0.y; a10 = 0.0 + p1.x; a11 = 0.0 + p1.y;
             if (cnt == 2) {
@@ -598,9 +608,14 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, int64_t n_
             }
         }
         if ((dbg & 8) && a00 != 1.2345e300) return;
+        const uint2 ft = fixT[i];
         double2* data2 = reinterpret_cast<double2*>(data);
         data2[f.x] = make_double2(a00, a01);
         data2[(int64_t)f.x + deg] = make_double2(a10, a11);
+        if (ft.x != 0xffffffffu && !(dbg & 16)) {                      // the mirror block (column node, row node): the transpose
+            data2[ft.x] = make_double2(a00, a10);
+            data2[(int64_t)ft.x + ft.y] = make_double2(a01, a11);
+        }
         return;
     }
     const int64_t i = (int64_t)(g - nb_k) * kBlock + threadIdx.x;

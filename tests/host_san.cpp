@@ -110,15 +110,16 @@ int main(int argc, char** argv) {
         for (const auto& row : ebs_np) {
             if (row[0] != n_p) continue;
             for (int k = 1; k < 4; ++k)
-                for (int variant = 0; variant < 3; ++variant) {
+                for (int variant = 0; variant < 4; ++variant) {
                     PatchOptions opt;
-                    opt.order = variant == 0 ? 0 : 1;
-                    opt.open_rows = variant == 2;
+                    opt.order = variant == 3 ? 2 : variant;                  // consecutive, Hilbert, 2 runs, 4 runs
+                    opt.runs = variant == 3 ? 4 : 2;
+                    opt.align = variant == 2 ? 16 : 1;
                     PatchPlan P;
                     r = build_patch_plan(S, n_p, n_e, n_n, elem.data(), xy.data(), row[k], opt, P);
                     const int bad = r == FEP_OK ? validate_patch_plan(P, S, n_p, n_e, n_n, elem.data()) : -1;
-                    std::printf("patch plan eb %d order %d open_rows %d: rc %d ok %d check %d patches %lld items %zu (<= %d per patch) open blocks %lld "
-                                "partials %lld (%.3f per element) open nodes %lld\n", row[k], opt.order, (int)opt.open_rows, r, (int)P.ok, bad,
+                    std::printf("patch plan eb %d order %d runs %d: rc %d ok %d check %d patches %lld items %zu (<= %d per patch) open blocks %lld "
+                                "partials %lld (%.3f per element) open nodes %lld\n", row[k], opt.order, opt.runs, r, (int)P.ok, bad,
                                 (long long)P.n_patch, P.items.size(), P.max_items, (long long)P.n_open, (long long)P.n_part,
                                 (double)P.n_part / (double)n_e, (long long)P.n_fopen);
                     if (r != FEP_OK || bad || !P.ok) rc = 1;

@@ -1,7 +1,7 @@
 """
 Sanitizer builds of the host-only native code (SURVEY section 5, row "race detection / sanitizers"): the threaded
-symbolic phase, the tile / gather plans of the P1 kernels, the opt-in node plan of P2 / Q2 and the multigrid
-aggregation (fem-elastoplasticity_amd/csrc/fep_host.h) are compiled into tests/host_san.cpp with
+symbolic phase, the tile / gather plans of the P1 kernels, the patch plans of the element route (every element type), the
+opt-in node plan of P2 / Q2 and the multigrid aggregation (fem-elastoplasticity_amd/csrc/fep_host.h) are compiled into tests/host_san.cpp with
   g++ -fsanitize=address,undefined   and   g++ -fsanitize=thread
 and driven on structured, Delaunay (row order and random numbering), tsx-tunnel and orphan-node meshes.  Every plan
 is checked against the mesh by fep_host::validate_p1_plan (all indices the kernels will form stay inside their
@@ -82,7 +82,9 @@ def test_host_native_code_under_sanitizers(fep, binaries, tmp_path, kind):
             assert res.returncode == 0 and 'result ok' in res.stdout, (name, res.stdout[-3000:])
             assert 'runtime error' not in res.stdout and 'Sanitizer' not in res.stdout, (name, res.stdout[-3000:])
             if elem.shape[0] == 3:
-                assert res.stdout.count('check 0') == 11, res.stdout               # 4 raw tilings + 7 plan variants, all validated
+                assert res.stdout.count(': rc 0 check 0 tiles') == 11, res.stdout  # 4 raw tilings + 7 plan variants, all validated
+            # the element route's patch plans: 3 patch sizes x 4 groupings, each replayed against the symbolic phase
+            assert len([l for l in res.stdout.splitlines() if l.startswith('patch plan') and ' ok 1 check 0 ' in l]) == 12, res.stdout
 
 
 def test_two_row_tiles_stage_fewer_elements_on_a_row_numbered_mesh(fep, binaries, tmp_path):
