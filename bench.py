@@ -3,7 +3,7 @@
 Benchmark of the hot path: element*quadrature-point updates per second for
 strain -> Drucker-Prager return map -> tangent-stiffness (CSR values) -> internal force.
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--cells C]
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--elem P1|P2|Q1|Q2] [--cells C] [--state S]
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` as a
@@ -19,6 +19,11 @@ the reference demo (DP:910-933), a synthetic displacement field that puts points
 Either way the mesh is sharded by contiguous element ranges, the hot path has no data-path collective and the
 only exchange is the RCCL all-reduce of the interface forces (one node row per cut).  At N > 1 the weak line
 also carries a `strong` object: the same K steps on the one-square mesh split N ways.
+
+`--elem P2` (default 1414 cells = 3 998 792 elements = 27 991 544 points; `--state random` puts the three branches i.i.d.
+on the points) is BASELINE configs[4]; its documented 8-GPU command is
+    python bench.py --gpus 8 --elem P2 --cells 1414 --state random --scaling strong
+(one square split over the ranks by contiguous element ranges; the element types other than P1 run the element route).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event timed on the launch
 stream, algorithmic bytes 537 B/update for P1: SURVEY 8d) and `cpu_baseline` (the NumPy oracle timed on this
@@ -39,6 +44,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_CELLS = 708                       # 2*708^2 = 1 002 528 P1 elements
+DEFAULT_CELLS = {'P1': 708, 'P2': 1414, 'Q1': 708, 'Q2': 708}          # P2: BASELINE configs[4] (3 998 792 elements)
+NQ = {'P1': 1, 'P2': 7, 'Q1': 4, 'Q2': 9}
 HBM_PEAK_GBS = 8000.0               # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s)
 ALG_BYTES = {'P1': 201 + 16 * 3 + 8 * 36 / 1, 'P2': 201 + 16 * 6 + 8 * 144 / 7,
              'Q1': 201 + 16 * 4 + 8 * 64 / 4, 'Q2': 201 + 16 * 8 + 8 * 256 / 9,
@@ -54,6 +61,7 @@ def dp_materials():
 def displacement(coord, seed=1, scale=1.0, state='bands'):
     """Synthetic state on the GLOBAL node set, periodic in y with the strip height, + noise.
     'bands'  (default) shear / compression / tension bands: ~18 % smooth and ~57 % apex points;
+    'random' the same with node noise of the size of the field's increments: the three branches i.i.d. over the points;
     'newton' a branch mix like the Newton iterates of configs[3] (tools/newton_bench.py: ~30 % smooth, < 0.1 % apex):
              slight uniform compression with a strong shear in the strip x < 3 (29 % smooth, no apex point)."""
     x, y = coord[0], np.mod(coord[1], 10.0)
@@ -61,6 +69,9 @@ def displacement(coord, seed=1, scale=1.0, state='bands'):
         U = scale * np.array([np.where(x < 3.0, 4.0e-4, 0.8e-4) * y, -2.0e-5 * y])
     else:
         U = scale * np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
+    if state == 'random':           # i.i.d. branch per point: worst-case divergence inside a wave (configs[4]); the noise
+        n_side = max(1.0, np.sqrt(coord.shape[1]) - 1)       # amplitude follows the node spacing so that strains stay O(1e-4)
+        U = U + np.random.default_rng(5).normal(0, 1.5e-4 * 10 / n_side, size=U.shape)
     U += np.random.default_rng(seed).normal(0, 2e-8, size=U.shape)
     return U
 
@@ -80,14 +91,40 @@ def cpu_baseline(fep, elem_type='P1', n_cells=N_CELLS, repeats=3, scale=1.0, sta
     U = displacement(coord, scale=scale, state=state)
     Ep = np.zeros((4, n_int))
     best = float('inf')
+    out = None
     for _ in range(repeats):
         t0 = time.perf_counter()
-        orc.hot_path(U, Ep, ctx)
+        out = orc.hot_path(U, Ep, ctx)
         best = min(best, time.perf_counter() - t0)
     return {'value': n_int / best, 'unit': 'updates/s', 'cores': 1, 'kind': 'port',
             'sample': f'oracle.hot_path (NumPy/SciPy, single thread) on the {n_cells}x{n_cells}-cell {elem_type} square '
                       f'({n_int} points, same field/materials), best of {repeats}, {best:.3f} s/pass; '
-                      f'host has {os.cpu_count()} cores'}
+                      f'host has {os.cpu_count()} cores'}, (out, K)
+
+
+def parity_vs_oracle(oracle_out, shard, torch):
+    """The checker's result of the cpu_baseline leg against what the GPU step left in the shard's buffers (same mesh, same
+    field): largest error of s, ds (relative to the array's largest entry), every row of K (relative to the row's largest
+    entry OR of the same row of K_elast, whichever is larger: the oracle forms K_elast + B^T (D_p - D_elast) B as the
+    reference does (DP:1050), so a row whose points are all at the apex is a difference of two numbers of K_elast's size
+    there — 1e-9 of round-off on an exact zero), F; ind_p must agree exactly.  Outside the timed region."""
+    import scipy.sparse as ssp
+    (E, cp, K_t, F), K_el = oracle_out
+    S = shard.S.cpu().numpy(); DS = shard.DS.cpu().numpy(); ind = shard.indp.cpu().numpy().astype(bool)
+    ip, ix = shard.ctx.pattern()
+    K = ssp.csr_matrix((shard.Kd.cpu().numpy(), ix, ip), shape=(shard.ctx.n_dof, shard.ctx.n_dof))
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+    D = abs(K - K_t).tocsr()
+    d = np.asarray(D.max(axis=1).todense()).ravel()
+    sc = np.maximum(np.asarray(abs(K_t).max(axis=1).todense()).ravel(), np.asarray(abs(K_el).max(axis=1).todense()).ravel())
+    k_rows = float(np.where(sc > 0, d / np.where(sc > 0, sc, 1.0), d).max())
+    F_g = shard.Fb[0].cpu().numpy()
+    errs = {'s': rel(S, cp['s']), 'ds': rel(DS, cp['ds']), 'K': float(d.max() / abs(K_t).max()), 'K_rows': k_rows,
+            'F': rel(F_g, np.asarray(F).ravel()),
+            'ind_p_mismatches': int(np.count_nonzero(ind != np.asarray(cp['ind_p']).ravel()))}
+    return errs
 
 
 def parse_args():
@@ -95,14 +132,18 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--cells', type=int, default=N_CELLS, help='cells per side of the square (per GPU when weak)')
+    ap.add_argument('--elem', choices=('P1', 'P2', 'Q1', 'Q2'), default='P1',
+                    help='element type: P1 = BASELINE configs[3] (default), P2 = configs[4]')
+    ap.add_argument('--cells', type=int, default=None,
+                    help='cells per side of the square (per GPU when weak); default 708 (P1, Q1, Q2), 1414 (P2)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--field-scale', type=float, default=1.0, help='multiplies the displacement field')
-    ap.add_argument('--state', choices=('bands', 'newton'), default='bands',
+    ap.add_argument('--state', choices=('bands', 'newton', 'random'), default='bands',
                     help="branch mix of the synthetic state: 'bands' ~18 %% smooth / 57 %% apex (default), 'newton' ~29 %% "
                          "smooth / no apex, like the Newton iterates of configs[3]")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-cells', type=int, default=None, help='cells per side of the CPU-baseline square (default: --cells)')
+    ap.add_argument('--cpu-cells', type=int, default=None,
+                    help='cells per side of the CPU-baseline square (default: --cells for P1, min(--cells, 354) otherwise: a bounded sample)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     return ap.parse_args()
 
@@ -126,7 +167,7 @@ class Shard:
     """One rank's part of a mesh: device context + device-resident state of the benchmark step."""
 
     def __init__(self, fep, torch, mesh, rank, world, dev, scale, two_buffers, state='bands'):
-        self.sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=dev.index)
+        self.sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=dev.index)   # element type from n_p
         ctx = self.ctx = self.sh.ctx
         ctx.set_materials(*dp_materials())
         n_int = self.n_int = ctx.n_int
@@ -172,7 +213,8 @@ def run(args):
 
     fep = importlib.import_module('fem-elastoplasticity_amd')
     fep.lib()                                      # fails loudly if the HIP extension is missing
-    N = args.cells
+    et = args.elem
+    N = args.cells if args.cells is not None else DEFAULT_CELLS[et]
     f64 = dict(dtype=torch.float64, device=dev)
     main = torch.cuda.current_stream()
     stream = main.cuda_stream
@@ -250,9 +292,10 @@ def run(args):
 
     # ---- the headline run ------------------------------------------------------------------------------------
     strong = args.scaling == 'strong'
-    mesh = fep.rect_mesh(N, N if strong else N * world, 'P1', 10, 10 if strong else 10 * world)
+    mesh = fep.rect_mesh(N, N if strong else N * world, et, 10, 10 if strong else 10 * world)
     shard = Shard(fep, torch, mesh, rank, world, dev, args.field_scale, world > 1, args.state)
-    n_total = int(mesh['elements'].shape[1])
+    n_el_total = int(mesh['elements'].shape[1])
+    n_total = n_el_total * NQ[et]                      # integration points = element*quadpt updates per step, all ranks
     dt, step = timed(shard, args.steps, args.warmup)
     cnt = shard.counts.clone()
     if world > 1:
@@ -273,27 +316,65 @@ def run(args):
               'kernels_ms': {'point': kms_kf['element'], 'assembly': kms_kf['csr'], 'force': kms_kf['force']},
               'note': 'fep_step_dev with s = ds = ind_p = counts = NULL (newton.py asks for K and F only)'}
 
+    # the mesh-free entry point on its own (fep_return_map_dev: the drop-in for construct_constitutive_problem, DP:604-757):
+    # strain, plastic strain and the four material arrays in, s / ds / ind_p / counts out = 193 B per point
+    rm = None
+    if world == 1:
+        from importlib import import_module
+        _lib = import_module('fem-elastoplasticity_amd._lib')
+        E = torch.empty((3, n_int), **f64)
+        ctx.step_dev(stream, shard.U.data_ptr(), ep=shard.Ep.data_ptr(), e_out=E.data_ptr(), s=shard.S.data_ptr())
+        mats = [torch.full((n_int,), v, **f64) for v in dp_materials()]
+
+        def rm_step():
+            _lib.check(_lib.lib().fep_return_map_dev(dev.index, stream, n_int, E.data_ptr(), 1, n_int, None, shard.Ep.data_ptr(),
+                                                     mats[0].data_ptr(), mats[1].data_ptr(), mats[2].data_ptr(), mats[3].data_ptr(),
+                                                     0, shard.S.data_ptr(), shard.DS.data_ptr(), shard.indp.data_ptr(),
+                                                     shard.counts.data_ptr()), 'fep_return_map_dev')
+        for _ in range(args.warmup):
+            rm_step()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(main)
+        for _ in range(args.steps):
+            rm_step()
+        ev1.record(main)
+        torch.cuda.synchronize()
+        rm_ms = ev0.elapsed_time(ev1) / args.steps
+        rm_cnt = [int(v) for v in shard.counts.cpu()]
+        rm = {'ms_per_call': rm_ms, 'points_per_s': n_int / (rm_ms * 1e-3), 'bytes_per_point': 193,
+              'GBps': 193.0 * n_int / (rm_ms * 1e-3) / 1e9, 'frac_of_peak': 193.0 * n_int / (rm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              'counts': rm_cnt, 'note': 'fep_return_map_dev (return_map_kernel + counts_reduce_kernel), per-point material arrays'}
+        assert rm_cnt == [n_smooth, n_apex], (rm_cnt, n_smooth, n_apex)
+        del E, mats
+
     # strong-scaling companion of a weak run (N > 1): ONE N x N square split over the ranks
     strong_line = None
     if world > 1 and not strong:
-        mesh_s = fep.rect_mesh(N, N, 'P1', 10, 10)
+        mesh_s = fep.rect_mesh(N, N, et, 10, 10)
         shard_s = Shard(fep, torch, mesh_s, rank, world, dev, args.field_scale, True, args.state)
         dt_s, step_s = timed(shard_s, args.steps, args.warmup)
         kms_s, _ = per_kernel(shard_s, step_s, args.steps)
         rk = gather_ranks([kms_s['element'], kms_s['csr'], float(shard_s.n_int)])
-        n_s = int(mesh_s['elements'].shape[1])
+        n_s = int(mesh_s['elements'].shape[1]) * NQ[et]
         strong_line = {'value': n_s * args.steps / dt_s, 'unit': 'updates/s', 'ms_per_step': dt_s / args.steps * 1e3,
                        'elements_total': n_s, 'scaling': 'strong',
-                       'per_rank': [{'elements': int(r[2]), 'point_ms': r[0], 'assembly_ms': r[1]} for r in rk],
+                       'per_rank': [{'points': int(r[2]), 'point_ms': r[0], 'assembly_ms': r[1]} for r in rk],
                        'exchange_ms': exchange_ms(shard_s)}
         shard_s.sh.close()
 
-    route = os.environ.get('FEP_P1_PATH', '') or 'node'
-    if route == 'coo':
-        # fused element kernel: strain + return map + K_e/f_e blocks (exactly the work SURVEY 8d prices)
-        k_ms = kms['element']
-        k_name = 'element_kernel<3,1,true> (strain + return map + K_e/f_e)'
-        others = {'csr_reduce_kernel': kms['csr'], 'force_reduce_kernel': kms['force']}
+    route = (os.environ.get('FEP_P1_PATH', '') or 'node') if et == 'P1' else 'element'
+    patch_form = os.environ.get('FEP_GEN_PATH', '') != 'coo'
+    if et != 'P1' or route == 'coo':
+        # element route: strain + return map + K_e blocks in one kernel; patch form (default): closed CSR blocks written by the
+        # same kernel, fixup_kernel for the node pairs on patch boundaries — the priced work is the pair
+        k_ms = kms['element'] + (kms['csr'] if patch_form else 0.0)
+        if patch_form:
+            k_name = f'element_kernel<{et}> (strain + return map + K_e in LDS + closed CSR blocks) + fixup_kernel (patch-boundary blocks)'
+            others = {'element_kernel': kms['element'], 'fixup_kernel': kms['csr']}
+        else:
+            k_name = f'element_kernel<{et}> (strain + return map + K_e/f_e blocks to HBM)'
+            others = {'csr_reduce_kernel': kms['csr'], 'force_reduce_kernel': kms['force']}
         per_k = None
     else:
         # node route: the priced work (return map + tangent assembly) is the PAIR of kernels; the
@@ -312,7 +393,7 @@ def run(args):
                                      'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                  'p1_node_kernel': {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
                                     'frac': b_node / (kms['csr'] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-    alg = ALG_BYTES['P1'] * n_int
+    alg = ALG_BYTES[et] * n_int
     achieved = alg / (k_ms * 1e-3) / 1e9
 
     if rank == 0:
@@ -323,18 +404,20 @@ def run(args):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('elements_per_gpu', 1002528) == n_int and route == 'node' and args.field_scale == 1.0 and args.state == 'bands':
+                if (et == 'P1' and tj.get('elements_per_gpu', 1002528) == n_int and route == 'node' and args.field_scale == 1.0
+                        and args.state == 'bands'):
                     traffic = tj.get('hbm_bytes_per_launch')
                     traffic_source = ('profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
                                       '`python bench.py`, 2*FETCH + WRITE per the gfx950 correction; not measured in this run)')
             except Exception:
                 traffic = None
-        label = ' (BASELINE configs[3])' if N == N_CELLS else ''
+        label = ' (BASELINE configs[3])' if (et, N) == ('P1', N_CELLS) else ' (BASELINE configs[4])' if (et, N) == ('P2', 1414) else ''
+        pts = '' if et == 'P1' else f' x {NQ[et]} points'
         if strong:
-            wl = (f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_total} P1 elements{label} split over '
+            wl = (f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_el_total} {et} elements{pts}{label} split over '
                   f'{world} GPU(s)')
         else:
-            wl = (f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_int} P1 elements per GPU{label}')
+            wl = (f'Plasticity2D_DP strip-footing square, {N}x{N} cells = {n_int // NQ[et]} {et} elements{pts} per GPU{label}')
         line = {
             'metric': 'element*quadpt updates/sec (return-map + K_tan assemble)',
             'value': n_total * args.steps / dt, 'unit': 'updates/s',
@@ -342,7 +425,8 @@ def run(args):
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wl + ', Drucker-Prager, strain->return map->K_tan CSR values->F per step',
-                       'elements_per_gpu': n_int, 'elements_total': n_total, 'nnz_per_gpu': ctx.nnz,
+                       'element_type': et, 'points_per_gpu': n_int, 'points_total': n_total, 'elements_total': n_el_total,
+                       'nnz_per_gpu': ctx.nnz,
                        'smooth_points': n_smooth, 'apex_points': n_apex, 'field_scale': args.field_scale, 'state': args.state,
                        'route': route,
                        'parallelism': f'element-shard x{world}, interface-force all-reduce' if world > 1 else 'single GPU'},
@@ -353,14 +437,26 @@ def run(args):
                          'kernels_ms': others, 'per_kernel': per_k},
         }
         if world > 1:
-            line['per_rank'] = [{'point_ms': r[0], 'assembly_ms': r[1]} for r in ranks_ms]
+            line['per_rank'] = [{'point_ms': r[0], 'assembly_ms': r[1]} for r in ranks_ms]      # first / second kernel of the step
             line['exchange_ms'] = x_ms
             if strong_line:
                 line['strong'] = strong_line
         if kf:
             line['kf_only'] = kf
+        if rm:
+            line['return_map_only'] = rm
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(fep, n_cells=args.cpu_cells or N, scale=args.field_scale, state=args.state)
+            cpu_n = args.cpu_cells or (N if et == 'P1' else min(N, 354))
+            line['cpu_baseline'], oracle_out = cpu_baseline(fep, et, n_cells=cpu_n, scale=args.field_scale, state=args.state)
+            if cpu_n == N:
+                # the checker ran the very mesh and field of the GPU step: compare (full-output pass once more, outside timing)
+                shard.step(stream, 0, True)
+                torch.cuda.synchronize()
+                errs = parity_vs_oracle(oracle_out, shard, torch)
+                line['parity_vs_oracle'] = errs
+                line['parity_max_rel'] = max(errs['s'], errs['ds'], errs['K'], errs['K_rows'], errs['F'])
+                if errs['ind_p_mismatches'] or line['parity_max_rel'] > 1e-11:      # reported, never fatal: the line is the product
+                    print(f'[bench] parity against the oracle outside the stated tolerance: {errs}', file=sys.stderr)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -23,6 +23,7 @@ from .build import build
 from .sharding import Partition, ShardedContext, element_ranges
 from .newton import solve_strip_footing, solve_tsx_tunnel, transform
 from .solver import KrylovSolver, build_amg_hierarchy
+from .dist_newton import DistributedPCG, solve_strip_footing_sharded
 from .midpoints import create_midpoints, create_midpoints_P2, create_midpoints_P4
 from .meshio import dump_free_dof_csv, load_tsx_mesh
 from . import plasticity2d_dp, tsx_tunnel, elasticity2d
@@ -31,6 +32,6 @@ __all__ = ['LagrangeElementType', 'ELEMENT_SHAPE', 'get_quadrature_volume', 'get
            'element_tables', 'assemble_mesh', 'square_mesh', 'rect_mesh', 'renumber_for_locality', 'Partition', 'ShardedContext', 'element_ranges', 'MeshContext', 'construct_constitutive_problem',
            'construct_constitutive_problem_tsx', 'get_elastic_stiffness_matrix', 'get_elastic_stiffness_matrix_el',
            'assemble_tangent', 'default_device', 'FepError', 'lib', 'lib_path', 'build',
-           'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'KrylovSolver', 'build_amg_hierarchy', 'create_midpoints', 'create_midpoints_P2',
+           'solve_strip_footing', 'solve_tsx_tunnel', 'transform', 'KrylovSolver', 'DistributedPCG', 'solve_strip_footing_sharded', 'build_amg_hierarchy', 'create_midpoints', 'create_midpoints_P2',
            'create_midpoints_P4', 'load_tsx_mesh', 'dump_free_dof_csv',
            'plasticity2d_dp', 'tsx_tunnel', 'elasticity2d']

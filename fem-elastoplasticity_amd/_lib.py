@@ -29,6 +29,7 @@ PROTOTYPES = {
     'fep_sync': (C.c_int, [C.c_int, C.c_void_p]),
     'fep_host_alloc': (C.c_int, [c_void_pp, C.c_int64]),
     'fep_host_free': (C.c_int, [C.c_void_p]),
+    'fep_host_trim': (C.c_int, []),
     'fep_return_map_host': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -125,7 +126,9 @@ class _PinnedBlock:
 
     def __init__(self, nbytes):
         p = C.c_void_p()
-        check(lib().fep_host_alloc(C.byref(p), nbytes), 'fep_host_alloc')
+        code = lib().fep_host_alloc(C.byref(p), nbytes)
+        if code != 0:
+            raise MemoryError(f'fep_host_alloc({nbytes}): {lib().fep_strerror(code).decode()}')
         self.ptr = p.value
 
     def __del__(self):
@@ -148,7 +151,12 @@ def pinned_empty(shape, dtype=None):
     for v in shape:
         n *= v
     nbytes = max(n * dt.itemsize, 1)
-    blk = _PinnedBlock(nbytes)
+    try:
+        blk = _PinnedBlock(nbytes)
+    except MemoryError:
+        # no page-locked memory left (the library has already given its idle blocks back and retried): an ordinary array
+        # does too — the *_host entry points stage pageable outputs through their pinned ring
+        return np.empty(shape, dtype=dt)
     buf = (C.c_char * nbytes).from_address(blk.ptr)
     buf._fep_owner = blk                               # ctypes objects take attributes: ties the block to the buffer
     return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)

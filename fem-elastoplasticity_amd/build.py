@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libfep_hip.so')
 SOURCES = ['fep_api.hip', 'fep_solver.hip']
-DEPS = ['fep_api.hip', 'fep_solver.hip', 'fep_common.h', 'fep_host.h', 'fep_kernels.hip.h', os.path.join('..', '..', 'include', 'fep.h')]
+DEPS = ['fep_api.hip', 'fep_solver.hip', 'fep_common.h', 'fep_host.h', 'fep_kernels.hip.h', 'fep_staging.h', os.path.join('..', '..', 'include', 'fep.h')]
 
 
 def hipcc_path():

@@ -66,6 +66,7 @@ struct fep_ctx {
     // one-kernel step (p1_fused_kernel): per-tile node lists / runs, per staged element its tile-local node indices + owner bit
     bool p1_fused = false, p1_fused_rng = false;
     bool asm_from_nodes = false;                        // FEP_P1_ASM=nodes: assembly kernel with geometry from LDS-staged nodes (measured slower)
+    bool p1_dma = false;                                // FEP_P1_DMA=1: node data and gather codes of the one-kernel step by LDS-DMA
     int fused_mode = 1;                                 // FEP_P1_FUSED=off|kf|all: 0 = never, 1 = only when no point output is wanted (default), 2 = always
     int lds_NL = 0;                                     // staged nodes per tile (max)
     int32_t *wg_nlist = nullptr, *wg_nrng = nullptr;
@@ -197,6 +198,29 @@ static E0 make_e0(const double* e0_h) {
     return z;
 }
 
+// Per-workgroup branch counters of the mesh-free return map (summed by counts_reduce_kernel): one grow-only buffer per
+// (device, stream), so that calls on different streams never share it.  The kernel used to add its two counters to the
+// caller's counts with global atomics — one contended pair per workgroup, the pattern that cost the P1 kernels 70 us per
+// launch in round 1.  Growing the buffer is an allocation: refused (FEP_ESTATE) while the stream is being captured.
+#include <map>
+#include <mutex>
+static int scratch_alloc_allowed(hipStream_t st);
+static int rm_scratch(int device, hipStream_t st, size_t n_blocks, uint2** out) {
+    static std::mutex m;
+    static auto& bufs = *new std::map<std::pair<int, void*>, std::pair<uint2*, size_t>>();
+    std::lock_guard<std::mutex> g(m);
+    auto& b = bufs[{device, (void*)st}];
+    if (b.second < n_blocks) {
+        FEP_TRY(scratch_alloc_allowed(st));
+        if (b.first) { HIP_TRY(hipFree(b.first)); b = {nullptr, 0}; }
+        const size_t cap = n_blocks + n_blocks / 4 + 64;
+        HIP_TRY(hipMalloc((void**)&b.first, cap * sizeof(uint2)));
+        b.second = cap;
+    }
+    *out = b.first;
+    return FEP_OK;
+}
+
 extern "C" int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
                                   const double* e_d, int64_t e_pt_stride, int64_t e_comp_stride,
                                   const double* e0_h, double* ep_prev_d,
@@ -206,12 +230,18 @@ extern "C" int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
     if (n_int > 0 && (!e_d || !shear_d || !bulk_d || !eta_d || !c_d)) return FEP_EINVAL;
     FEP_TRY(fep_set_device(device_id));
     hipStream_t st = (hipStream_t)stream;
-    if (counts_d) HIP_TRY(hipMemsetAsync(counts_d, 0, 2 * sizeof(int64_t), st));
-    if (n_int == 0) return FEP_OK;
-    hipLaunchKernelGGL(return_map_kernel, dim3(grid_for(n_int, kBlock)), dim3(kBlock), 0, st,
+    if (n_int == 0) { if (counts_d) HIP_TRY(hipMemsetAsync(counts_d, 0, 2 * sizeof(int64_t), st)); return FEP_OK; }
+    const unsigned n_blocks = grid_for(n_int, kBlock);
+    uint2* blk = nullptr;
+    if (counts_d) FEP_TRY(rm_scratch(device_id, st, n_blocks, &blk));
+    hipLaunchKernelGGL(return_map_kernel, dim3(n_blocks), dim3(kBlock), 0, st,
                        n_int, e_d, e_pt_stride, e_comp_stride, make_e0(e0_h), ep_prev_d,
-                       shear_d, bulk_d, eta_d, c_d, accept, s_d, ds_d, ind_p_d, (unsigned long long*)counts_d);
+                       shear_d, bulk_d, eta_d, c_d, accept, s_d, ds_d, ind_p_d, blk);
     HIP_TRY(hipGetLastError());
+    if (counts_d) {
+        hipLaunchKernelGGL(counts_reduce_kernel, dim3(1), dim3(1024), 0, st, (int)n_blocks, blk, (unsigned long long*)counts_d);
+        HIP_TRY(hipGetLastError());
+    }
     return FEP_OK;
 }
 
@@ -237,6 +267,10 @@ extern "C" int fep_host_free(void* ptr_h) {
     try { return fep_stage::pinned().release(ptr_h); }
     catch (...) { return FEP_ENOMEM; }
 }
+extern "C" int fep_host_trim(void) {
+    try { return fep_stage::pinned().trim(); }
+    catch (...) { return FEP_ENOMEM; }
+}
 
 static int return_map_host_impl(int device_id, int64_t n_int,
                                 const double* e_h, int64_t e_pt_stride, int64_t e_comp_stride,
@@ -254,7 +288,7 @@ static int return_map_host_impl(int device_id, int64_t n_int,
     const int64_t nb = n_int * (int64_t)sizeof(double);
     fep_stage::Engine* E = nullptr;
     FEP_TRY(fep_stage::engine(device_id, &E));
-    std::lock_guard<std::mutex> lock(E->call);
+    fep_stage::EngineCall call(E);                      // drains the engine on every exit that is not a completed finish()
     void *e = nullptr, *ep = nullptr, *sh, *bu, *et, *cc, *s = nullptr, *ds = nullptr, *ip = nullptr, *cnt;
     FEP_TRY(E->buffer(0, span * (int64_t)sizeof(double), &e));
     if (ep_prev_h) FEP_TRY(E->buffer(1, 4 * nb, &ep));
@@ -282,7 +316,7 @@ static int return_map_host_impl(int device_id, int64_t n_int,
     if (ind_p_h) FEP_TRY(E->d2h(ind_p_h, ip, (size_t)n_int));
     if (counts_h) FEP_TRY(E->d2h(counts_h, cnt, 2 * sizeof(int64_t)));
     if (accept && ep_prev_h) FEP_TRY(E->d2h(ep_prev_h, ep, (size_t)(4 * nb)));
-    const int rf = E->finish();
+    const int rf = call.finish();
     if (timing)
         std::fprintf(stderr, "[fep] return_map_host: done after %.3f ms\n",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -439,6 +473,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
             c->p1_lds = P.lds; c->lds_L = P.L; c->lds_C = P.C; c->p1_rng = P.rng; c->p1_pk = P.pk;
             c->p1_fused = P.fused; c->p1_fused_rng = P.fused_rng; c->lds_NL = P.NL;
             if (const char* am = std::getenv("FEP_P1_ASM")) c->asm_from_nodes = std::strcmp(am, "nodes") == 0;
+            if (const char* dm = std::getenv("FEP_P1_DMA")) c->p1_dma = std::strcmp(dm, "0") != 0;
             if (const char* fm = std::getenv("FEP_P1_FUSED"))
                 c->fused_mode = std::strcmp(fm, "off") == 0 ? 0 : std::strcmp(fm, "kf") == 0 ? 1 : 2;
             CK(upload(&c->perm2, P.perm2.data(), (int64_t)P.perm2.size()));
@@ -915,18 +950,21 @@ static int launch_point(fep_ctx* c, hipStream_t st, const double* u, E0 e0, doub
 // P1, one kernel per step (non-accepting calls with K and/or F wanted): p1_fused_kernel
 static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, const double* ep, double* eout, double* s,
                            double* ds, uint8_t* indp, double* k_data, double* f_out, unsigned long long* counts_d) {
-    const size_t lds_stage = (((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * 2 + 15) & ~(size_t)15) +
-                             (size_t)c->lds_NL * 2 * sizeof(double2);
+    const bool dma = c->p1_dma;
+    const size_t Cp = dma ? ((size_t)c->lds_C + 127) & ~(size_t)127 : (size_t)c->lds_C;
+    const size_t NLp = dma ? ((size_t)c->lds_NL + 63) & ~(size_t)63 : (size_t)c->lds_NL;
+    const size_t lds_stage = (((size_t)c->lds_L * 15 * sizeof(double) + Cp * 2 + 15) & ~(size_t)15) + NLp * 2 * sizeof(double2);
     const size_t lds = std::max(lds_stage, (size_t)c->tile * 3 * sizeof(double2));
     const int n_wg = c->n_wg_p1;
     const int chunk = (n_wg + 7) / 8;
     const bool full = eout || s || ds || indp;
-#define FUSED4(FULL, RNG, EPT, NPT)                                                                                      \
+#define FUSED4(FULL, RNG, EPT, NPT)  do { if (dma) FUSED5(FULL, RNG, EPT, NPT, true); else FUSED5(FULL, RNG, EPT, NPT, false); } while (0)
+#define FUSED5(FULL, RNG, EPT, NPT, DMA)                                                                                 \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void*)p1_fused_kernel<FULL, 256, RNG, EPT, NPT>,                          \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_fused_kernel<FULL, 256, RNG, EPT, NPT, false, DMA>,              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((p1_fused_kernel<FULL, 256, RNG, EPT, NPT>), dim3(8 * chunk), dim3(256), lds, st,             \
+        hipLaunchKernelGGL((p1_fused_kernel<FULL, 256, RNG, EPT, NPT, false, DMA>), dim3(8 * chunk), dim3(256), lds, st, \
                            c->n_e, c->lds_L, c->lds_C, c->lds_NL, c->perm_l, c->wg_elist, (const int4*)c->wg_rng,        \
                            c->wg_nlist, (const int4*)c->wg_nrng, c->el_nodes, c->pk, c->tdesc, c->xy,                   \
                            c->p1tab, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu, eout, s, ds, indp, k_data,      \
@@ -940,12 +978,22 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
     else { if (c->p1_fused_rng) FUSED3(false, true); else FUSED3(false, false); }
 #undef FUSED3
 #undef FUSED4
+#undef FUSED5
     HIP_TRY(hipGetLastError());
     if (counts_d) {
         hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(256), 0, st, c->slot_counts, counts_d);
         HIP_TRY(hipGetLastError());
     }
     return FEP_OK;
+}
+
+// The internal ds / s scratch of the two-kernel routes is allocated on first use.  Allocating is illegal while the
+// stream is being captured into a graph: such a call is refused (FEP_ESTATE) instead of breaking the capture — run the
+// same call once outside the capture first (fep.h, fep_step_dev).
+static int scratch_alloc_allowed(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return FEP_OK; }
+    return cs == hipStreamCaptureStatusNone ? FEP_OK : FEP_ESTATE;
 }
 
 extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const double* e0_h,
@@ -973,11 +1021,11 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
     if (c->p1_node) {
         // the assembly kernel consumes ds / s from HBM: use internal buffers when the caller wants neither
         if (k_data_d && !ds_d) {
-            if (!c->ds_int) FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int));
+            if (!c->ds_int) { FEP_TRY(scratch_alloc_allowed(st)); FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int)); }
             ds_d = c->ds_int;
         }
         if (f_out_d && !s_d) {
-            if (!c->s_int) FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int));
+            if (!c->s_int) { FEP_TRY(scratch_alloc_allowed(st)); FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int)); }
             s_d = c->s_int;
         }
         FEP_TRY(prof_mark(c, st));
@@ -991,11 +1039,11 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
     }
     if (c->gn) {
         if (k_data_d && !ds_d) {
-            if (!c->ds_int) FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int));
+            if (!c->ds_int) { FEP_TRY(scratch_alloc_allowed(st)); FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int)); }
             ds_d = c->ds_int;
         }
         if (f_out_d && !s_d) {
-            if (!c->s_int) FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int));
+            if (!c->s_int) { FEP_TRY(scratch_alloc_allowed(st)); FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int)); }
             s_d = c->s_int;
         }
         FEP_TRY(prof_mark(c, st));
@@ -1064,7 +1112,7 @@ static int step_host_impl(fep_ctx* c, bool u_planar, const double* u_h, const do
     const int64_t nb = c->n_int * (int64_t)sizeof(double);
     fep_stage::Engine* E = nullptr;
     FEP_TRY(fep_stage::engine(c->device, &E));
-    std::lock_guard<std::mutex> lock(E->call);
+    fep_stage::EngineCall call(E);                      // drains the engine on every exit that is not a completed finish()
     void *u, *ep = nullptr, *eo = nullptr, *s = nullptr, *ds = nullptr, *ip = nullptr, *kd = nullptr, *f = nullptr, *cnt;
     FEP_TRY(ctx_buf(c, 0, c->n_dof * (int64_t)sizeof(double), &u));
     if (ep_prev_h) FEP_TRY(ctx_buf(c, 1, 4 * nb, &ep));
@@ -1089,7 +1137,7 @@ static int step_host_impl(fep_ctx* c, bool u_planar, const double* u_h, const do
     if (ind_p_h) FEP_TRY(E->d2h(ind_p_h, ip, (size_t)c->n_int));
     if (counts_h) FEP_TRY(E->d2h(counts_h, cnt, 2 * sizeof(int64_t)));
     if (accept && ep_prev_h) FEP_TRY(E->d2h(ep_prev_h, ep, (size_t)(4 * nb)));
-    return E->finish();
+    return call.finish();
 }
 
 extern "C" int fep_step_host(fep_ctx* c, const double* u_h, const double* e0_h, double* ep_prev_h, int accept,
@@ -1111,7 +1159,7 @@ static int assemble_host_impl(fep_ctx* c, const double* ds_h, const double* s_h,
     const int64_t nb = c->n_int * (int64_t)sizeof(double);
     fep_stage::Engine* E = nullptr;
     FEP_TRY(fep_stage::engine(c->device, &E));
-    std::lock_guard<std::mutex> lock(E->call);
+    fep_stage::EngineCall call(E);                      // drains the engine on every exit that is not a completed finish()
     void *ds = nullptr, *s = nullptr, *kd = nullptr, *f = nullptr;
     if (ds_h) { FEP_TRY(ctx_buf(c, 4, 9 * nb, &ds)); FEP_TRY(E->h2d(ds, ds_h, (size_t)(9 * nb))); }
     if (s_h) { FEP_TRY(ctx_buf(c, 3, 4 * nb, &s)); FEP_TRY(E->h2d(s, s_h, (size_t)(3 * nb))); }
@@ -1120,7 +1168,7 @@ static int assemble_host_impl(fep_ctx* c, const double* ds_h, const double* s_h,
     FEP_TRY(fep_assemble_dev(c, E->stream, (const double*)ds, (const double*)s, (double*)kd, (double*)f));
     if (k_data_h) FEP_TRY(E->d2h(k_data_h, kd, (size_t)c->nnz * sizeof(double)));
     if (f_out_h) FEP_TRY(E->d2h(f_out_h, f, (size_t)c->n_dof * sizeof(double)));
-    return E->finish();
+    return call.finish();
 }
 
 extern "C" int fep_assemble_host(fep_ctx* c, const double* ds_h, const double* s_h, double* k_data_h, double* f_out_h) {
@@ -1161,14 +1209,14 @@ static int transform_host_impl(fep_ctx* c, const double* q_int_h, double* q_node
     FEP_TRY(fep_set_device(c->device));
     fep_stage::Engine* E = nullptr;
     FEP_TRY(fep_stage::engine(c->device, &E));
-    std::lock_guard<std::mutex> lock(E->call);
+    fep_stage::EngineCall call(E);                      // drains the engine on every exit that is not a completed finish()
     void *q, *o;
     FEP_TRY(ctx_buf(c, 9, c->n_int * (int64_t)sizeof(double), &q));
     FEP_TRY(ctx_buf(c, 10, c->n_n * (int64_t)sizeof(double), &o));
     FEP_TRY(E->h2d(q, q_int_h, (size_t)c->n_int * sizeof(double)));
     FEP_TRY(fep_transform_dev(c, E->stream, (const double*)q, (double*)o));
     FEP_TRY(E->d2h(q_node_h, o, (size_t)c->n_n * sizeof(double)));
-    return E->finish();
+    return call.finish();
 }
 
 extern "C" int fep_transform_host(fep_ctx* c, const double* q_int_h, double* q_node_h) {

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <system_error>
 #include <thread>
@@ -34,19 +35,28 @@ inline int worker_count() {
 
 // f(lo, hi, worker) over [0, n) in contiguous chunks, one per worker thread.  If a thread cannot be started
 // (process / thread limits) its chunk runs on the calling thread: never throws std::system_error to the caller.
+// An exception thrown INSIDE a chunk (std::bad_alloc of a work buffer at BASELINE configs[4] sizes on a small host) is
+// caught in its thread — an exception leaving a std::thread body is std::terminate — and rethrown here, on the calling
+// thread, once every worker has been joined; fep_ctx_create turns it into FEP_ENOMEM.
 template <class F> void parallel_chunks(int64_t n, F&& f) {
     const int nw = (int)std::max<int64_t>(1, std::min<int64_t>(worker_count(), n));
     std::vector<std::thread> th;
     th.reserve(nw);
     std::vector<int> inline_chunks;
+    std::vector<std::exception_ptr> err((size_t)nw);
+    auto guarded = [&f, &err](int64_t lo, int64_t hi, int w) {
+        try { f(lo, hi, w); } catch (...) { err[(size_t)w] = std::current_exception(); }
+    };
     for (int w = 1; w < nw; ++w) {
         const int64_t lo = n * w / nw, hi = n * (w + 1) / nw;
-        try { th.emplace_back([&f, lo, hi, w]() { f(lo, hi, w); }); }
+        try { th.emplace_back([&guarded, lo, hi, w]() { guarded(lo, hi, w); }); }
         catch (const std::system_error&) { inline_chunks.push_back(w); }
     }
-    f(0, n / nw, 0);
-    for (int w : inline_chunks) f(n * w / nw, n * (w + 1) / nw, w);
+    guarded(0, n / nw, 0);
+    for (int w : inline_chunks) guarded(n * w / nw, n * (w + 1) / nw, w);
     for (auto& t : th) t.join();
+    for (const std::exception_ptr& e : err)
+        if (e) std::rethrow_exception(e);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1060,11 +1070,15 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
     };
     // (two workers never touch the same fix entry field: a block's partials come from different patches, each patch
     // belongs to one worker and writes its own rank)
+    std::vector<std::exception_ptr> ferr((size_t)nw);
+    auto finish_guarded = [&](int w) { try { finish(w); } catch (...) { ferr[(size_t)w] = std::current_exception(); } };
     for (int w = 1; w < nw; ++w) {
-        try { th.emplace_back(finish, w); } catch (const std::system_error&) { finish(w); }
+        try { th.emplace_back(finish_guarded, w); } catch (const std::system_error&) { finish_guarded(w); }
     }
-    finish(0);
+    finish_guarded(0);
     for (auto& t : th) t.join();
+    for (const std::exception_ptr& e : ferr)
+        if (e) std::rethrow_exception(e);
     P.ok = true;
     return FEP_OK;
 }

@@ -175,7 +175,7 @@ return_map_kernel(int64_t n, const double* __restrict__ e, int64_t eps, int64_t 
                   double* __restrict__ ep, const double* __restrict__ shear, const double* __restrict__ bulk,
                   const double* __restrict__ eta, const double* __restrict__ cc, int accept,
                   double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp,
-                  unsigned long long* counts) {
+                  uint2* blk_counts) {
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     int branch = 0;
     if (k < n) {
@@ -187,7 +187,7 @@ return_map_kernel(int64_t n, const double* __restrict__ e, int64_t eps, int64_t 
         store_point(k, n, s, d, branch, S, DS, indp);
         if (accept && ep && branch) { ep[k] = p[0]; ep[n + k] = p[1]; ep[2 * n + k] = p[2]; ep[3 * n + k] = p[3]; }
     }
-    count_branches(branch, counts, nullptr);
+    count_branches(branch, nullptr, blk_counts);      // per-workgroup counters, summed by counts_reduce_kernel (no global atomics)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -937,6 +937,16 @@ p1_node_kernel(int64_t n_blk, int64_t n_e, const int32_t* __restrict__ segptr, c
 // has exactly one segment (its blocks are first_block + lane).
 constexpr int kSegMax = 4;
 
+// LDS-DMA (global_load_lds): the lane's 16 / 4 bytes at `g` go straight to LDS at wave_base + lane * size — no VGPR, no
+// ds_write.  `wave_base` must be wave-uniform; the data is visible to ds_read after s_waitcnt vmcnt + a barrier
+// (__syncthreads() waits for vmcnt(0)).
+__device__ __forceinline__ void glds16(const void* g, void* wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)wave_base, 4, 0, 0);
+}
+
 static_assert(kSegMax == 4, "the tile descriptor names its four segments");
 // plain ints (no HIP vector types, no arrays): the descriptor stays in scalar registers
 struct TileDesc {
@@ -1177,7 +1187,9 @@ p1_node_lds_kernel(int64_t n_e, int L, int C, const int32_t* __restrict__ segptr
 // FROM_DS = true: the assembly-only form (fep_assemble_dev, and the second kernel of a full-output / accepting step):
 // w*DS and w*s come from the caller's ds / s arrays (`DSin`, `Sin`) instead of the return map, the geometry still from
 // the tile's LDS-staged nodes — 48 bytes per staged element less to fetch than p1_node_lds_kernel's geometry record.
-template <bool FULL, int TPB, bool RNG, int EPT, int NPT, bool FROM_DS = false>
+// DMA = true: the staged nodes' coordinates / displacements and the tile's gather codes go to LDS by LDS-DMA (the code
+// region is padded to 64 words and the node regions to 64 entries: a wave's 64 lanes always land inside their region).
+template <bool FULL, int TPB, bool RNG, int EPT, int NPT, bool FROM_DS = false, bool DMA = false>
 __global__ void __launch_bounds__(TPB, (!FULL && EPT == 1) ? 8 : 1)     // K/F-only: 64 VGPRs, 8 tiles of 4 waves per CU
 p1_fused_kernel(int64_t n_e, int L, int C, int NL,
                 const uint16_t* __restrict__ perm_l, const int32_t* __restrict__ wg_elist, const int4* __restrict__ rng,
@@ -1247,12 +1259,22 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
     }
     // (2) loads, all issued before the first use: node data, the slots' node words / plastic strain / materials
     const int n_el = td.n_el, n_nd = td.n_nd;           // this tile's staged elements / nodes (<= L / NL)
+    const int Cp = DMA ? (C + 127) & ~127 : C, NLp = DMA ? (NL + 63) & ~63 : NL;      // padded code / node regions (see above)
+    uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
+    uint32_t* codes32 = reinterpret_cast<uint32_t*>(rec + 15 * L);
+    double2* lxy = reinterpret_cast<double2*>(reinterpret_cast<char*>(rec) + (((size_t)15 * L * 8 + (size_t)Cp * 2 + 15) & ~(size_t)15));
+    double2* lu = lxy + NLp;
     double2 nxy[NPT], nu[NPT];
 #pragma unroll
     for (int r = 0; r < NPT; ++r) {
         if (r * TPB + (int)(threadIdx.x & ~63u) >= n_nd) continue;   // wave-uniform: idle waves issue nothing
-        nxy[r] = *reinterpret_cast<const double2*>(xy + 2 * nd[r]);
-        if (!FROM_DS) nu[r] = *reinterpret_cast<const double2*>(U + 2 * nd[r]);
+        if (DMA) {
+            glds16(xy + 2 * nd[r], lxy + r * TPB + (int)(threadIdx.x & ~63u));
+            if (!FROM_DS) glds16(U + 2 * nd[r], lu + r * TPB + (int)(threadIdx.x & ~63u));
+        } else {
+            nxy[r] = *reinterpret_cast<const double2*>(xy + 2 * nd[r]);
+            if (!FROM_DS) nu[r] = *reinterpret_cast<const double2*>(U + 2 * nd[r]);
+        }
     }
     uint32_t enw[EPT];
     double pv[EPT][4], mv[EPT][4];
@@ -1284,24 +1306,25 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
     for (int r = 0; r < CWPT; ++r) {
         const int i = r * TPB + (int)threadIdx.x;
         cd[r] = 0u;
-        if (r * TPB + (int)(threadIdx.x & ~63u) < CW) cd[r] = codes_w[i < CW ? i : 0];
+        if (r * TPB + (int)(threadIdx.x & ~63u) < CW) {
+            if (DMA) glds4(codes_w + (i < CW ? i : 0), codes32 + r * TPB + (int)(threadIdx.x & ~63u));
+            else cd[r] = codes_w[i < CW ? i : 0];
+        }
     }
-    // (4) node data and codes -> LDS
-    uint16_t* codes = reinterpret_cast<uint16_t*>(rec + 15 * L);
-    uint32_t* codes32 = reinterpret_cast<uint32_t*>(rec + 15 * L);
-    double2* lxy = reinterpret_cast<double2*>(reinterpret_cast<char*>(rec) + (((size_t)15 * L * 8 + (size_t)C * 2 + 15) & ~(size_t)15));
-    double2* lu = lxy + NL;
+    // (4) node data and codes -> LDS (already on their way with DMA)
+    if (!DMA) {
 #pragma unroll
-    for (int r = 0; r < NPT; ++r) {
-        const int i = r * TPB + (int)threadIdx.x;
-        if (i < n_nd) { lxy[i] = nxy[r]; if (!FROM_DS) lu[i] = nu[r]; }
-    }
+        for (int r = 0; r < NPT; ++r) {
+            const int i = r * TPB + (int)threadIdx.x;
+            if (i < n_nd) { lxy[i] = nxy[r]; if (!FROM_DS) lu[i] = nu[r]; }
+        }
 #pragma unroll
-    for (int q = 0; q < CWPT; ++q) {
-        const int ci = q * TPB + (int)threadIdx.x;
-        if (ci < CW) codes32[ci] = cd[q];
+        for (int q = 0; q < CWPT; ++q) {
+            const int ci = q * TPB + (int)threadIdx.x;
+            if (ci < CW) codes32[ci] = cd[q];
+        }
     }
-    __syncthreads();
+    __syncthreads();                                    // (waits for vmcnt(0): the DMA has landed)
     // (5) per staged element: geometry, strain, return map (p1_point_kernel's statements), operands -> LDS
     unsigned int n_sm = 0u, n_ap = 0u;
 #pragma unroll

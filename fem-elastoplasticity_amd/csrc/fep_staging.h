@@ -10,8 +10,14 @@
 //     a few persistent worker threads copy chunk i+1 into its slot while the DMA engine moves chunk i
 //     (hipMemcpyAsync); pageable outputs take the same ring the other way;
 //   * everything is ordered on one stream per device; one hipStreamSynchronize at the end of the call.
+// The three classes use six HIP calls (hipHostMalloc / hipHostFree / hipMalloc / hipFree / hipMemcpyAsync / stream and
+// event handling).  tests/host_san.cpp defines FEP_STAGING_HOST_STUB and supplies host stand-ins for them (plain memory,
+// synchronous copies, a switch that makes the next copy fail), so that PinnedCache, CopyPool and Engine run under
+// ThreadSanitizer / AddressSanitizer on the CPU.
 #pragma once
+#ifndef FEP_STAGING_HOST_STUB
 #include "fep_common.h"
+#endif
 
 #include <algorithm>
 #include <condition_variable>
@@ -30,23 +36,50 @@ namespace fep_stage {
 // ---------------------------------------------------------------------------------------
 struct PinnedCache {
     std::mutex m;
-    std::map<const char*, size_t> live;                 // every block handed out or cached: base -> bytes
+    struct Block { size_t bytes; bool idle; };
+    std::map<const char*, Block> live;                  // every block handed out or cached: base -> (bytes, in the idle list?)
     std::multimap<size_t, void*> idle;                  // returned blocks, reused for requests of the same size
     size_t idle_bytes = 0;
     static constexpr size_t kIdleCap = (size_t)4 << 30;
 
+    // frees every idle block (called when the runtime refuses to pin more memory; also what a caller can do to give the
+    // pinned pages back: fep_host_trim)
+    int trim() {
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (auto& kv : idle) { drop.push_back(kv.second); live.erase((const char*)kv.second); }
+            idle.clear();
+            idle_bytes = 0;
+        }
+        int r = FEP_OK;
+        for (void* p : drop)
+            if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); r = FEP_EHIP; }
+        return r;
+    }
     int alloc(void** out, size_t bytes) {
         if (bytes == 0) bytes = 1;
         {
             std::lock_guard<std::mutex> g(m);
             auto it = idle.find(bytes);
-            if (it != idle.end()) { *out = it->second; idle_bytes -= bytes; idle.erase(it); return FEP_OK; }
+            if (it != idle.end()) {
+                *out = it->second;
+                live[(const char*)it->second].idle = false;
+                idle_bytes -= bytes;
+                idle.erase(it);
+                return FEP_OK;
+            }
         }
         void* p = nullptr;
         hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {                           // pinned memory is a limited resource: give the idle blocks back, retry once
+            (void)hipGetLastError();
+            (void)trim();
+            e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        }
         if (e != hipSuccess) { fep_g_last_hip = (int)e; (void)hipGetLastError(); return e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; }
         std::lock_guard<std::mutex> g(m);
-        live[(const char*)p] = bytes;
+        live[(const char*)p] = Block{bytes, false};
         *out = p;
         return FEP_OK;
     }
@@ -54,9 +87,9 @@ struct PinnedCache {
         if (!p) return FEP_OK;
         std::unique_lock<std::mutex> g(m);
         auto it = live.find((const char*)p);
-        if (it == live.end()) return FEP_EINVAL;
-        const size_t bytes = it->second;
-        if (idle_bytes + bytes <= kIdleCap) { idle.emplace(bytes, p); idle_bytes += bytes; return FEP_OK; }
+        if (it == live.end() || it->second.idle) return FEP_EINVAL;          // not ours, or released twice
+        const size_t bytes = it->second.bytes;
+        if (idle_bytes + bytes <= kIdleCap) { it->second.idle = true; idle.emplace(bytes, p); idle_bytes += bytes; return FEP_OK; }
         live.erase(it);
         g.unlock();
         HIP_TRY(hipHostFree(p));
@@ -68,7 +101,7 @@ struct PinnedCache {
         auto it = live.upper_bound((const char*)p);
         if (it == live.begin()) return false;
         --it;
-        return (const char*)p + bytes <= it->first + it->second;
+        return (const char*)p + bytes <= it->first + it->second.bytes;
     }
 };
 inline PinnedCache& pinned() { static PinnedCache c; return c; }
@@ -78,7 +111,7 @@ inline PinnedCache& pinned() { static PinnedCache c; return c; }
 // ---------------------------------------------------------------------------------------
 class CopyPool {
     std::vector<std::thread> th;
-    std::mutex m;
+    std::mutex m, submit;
     std::condition_variable cv_job, cv_done;
     void (*job)(void*, int, int) = nullptr;             // job(ctx, worker, n_workers)
     void* job_ctx = nullptr;
@@ -99,7 +132,7 @@ class CopyPool {
             g.unlock();
             f(c, w, n);
             g.lock();
-            if (--pending == 0) cv_done.notify_one();
+            if (--pending == 0) cv_done.notify_all();
         }
     }
     struct Cpy { char* dst; const char* src; size_t bytes; };
@@ -133,8 +166,11 @@ public:
         for (auto& t : th) t.join();
     }
     // f(ctx, w, n) for w = 0..n-1, worker 0 on the calling thread; returns when all are done
+    // One job at a time: the pool is process-wide, and two host threads driving *_host calls on two GPUs (ctypes
+    // releases the GIL) would otherwise overwrite each other's job before the workers woke up.
     void parallel(void (*f)(void*, int, int), void* ctx) {
         if (n == 1) { f(ctx, 0, 1); return; }
+        std::lock_guard<std::mutex> one(submit);
         {
             std::lock_guard<std::mutex> g(m);
             job = f; job_ctx = ctx; pending = n - 1; ++gen;
@@ -244,12 +280,32 @@ struct Engine {
         HIP_TRY(hipStreamSynchronize(stream));
         return FEP_OK;
     }
+    // After a failed call: wait for whatever is still in flight and FORGET the parked device -> host chunks — their
+    // destinations belong to the failed call's output arrays, which the caller is about to free (a later settle() must
+    // never copy into them).  The ring restarts at slot 0.
+    void drain() {
+        (void)hipStreamSynchronize(stream);
+        (void)hipGetLastError();
+        for (int i = 0; i < kSlots; ++i) pend[i] = Pending();
+        next = 0;
+    }
+};
+
+// Scope of one *_host entry point: holds the engine's call lock; unless finish() succeeded (disarm) the engine is drained
+// on the way out, whatever the exit path (error return or exception).
+struct EngineCall {
+    Engine* E;
+    std::unique_lock<std::mutex> lock;
+    bool armed = true;
+    explicit EngineCall(Engine* e) : E(e), lock(e->call) {}
+    ~EngineCall() { if (armed) E->drain(); }
+    int finish() { const int r = E->finish(); if (r == FEP_OK) armed = false; return r; }
 };
 
 // engine of a device (created on first use, lives as long as the library)
 inline int engine(int device, Engine** out) {
     static std::mutex m;
-    static std::map<int, Engine*> all;
+    static std::map<int, Engine*>& all = *new std::map<int, Engine*>();      // never destroyed: engines outlive static destructors
     std::lock_guard<std::mutex> g(m);
     auto it = all.find(device);
     if (it == all.end()) {

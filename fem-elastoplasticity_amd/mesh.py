@@ -17,17 +17,6 @@ import numpy as np
 from .tables import LagrangeElementType, _coerce
 
 
-def _boundary(coord, size_xy):
-    """Footing / free-DOF masks, DP:178-184."""
-    footing = np.logical_and(coord[1, :] == size_xy, coord[0, :] <= 1.0001)
-    dirichlet = np.zeros(coord.shape)
-    dirichlet[1, footing] = 1
-    Q = coord > 0
-    Q[1, footing] = 0
-    Q[0, coord[0, :] == size_xy] = 0
-    return dirichlet, Q
-
-
 def square_mesh(n_seg, element_type, size_xy=10):
     """Mesh of [0,size_xy]^2 with `n_seg` cells per side.
 
@@ -38,89 +27,71 @@ def square_mesh(n_seg, element_type, size_xy=10):
 
 
 def rect_mesh(n_x, n_y, element_type, size_x=10, size_y=10):
-    """Same numbering on an n_x by n_y cell rectangle [0,size_x]x[0,size_y] (P1/Q1 only); used for
-    the multi-GPU strips of the benchmark.  Boundary masks follow DP:178-184 with the footing on the
-    top edge y == size_y and rollers on x == size_x."""
-    t = _coerce(element_type)
-    if n_x == n_y and size_x == size_y:
-        return _square(int(n_x), t, size_x)
-    if t not in (LagrangeElementType.P1, LagrangeElementType.Q1):
-        raise ValueError('rectangles are generated for P1/Q1 only')
-    Mx, My = int(n_x) + 1, int(n_y) + 1
-    xs = np.linspace(0, size_x, Mx)
-    ys = np.linspace(0, size_y, My)
-    coord = np.array([np.tile(xs, My), np.repeat(ys, Mx)])
-    ci, cj = np.meshgrid(np.arange(int(n_x)), np.arange(int(n_y)), indexing='xy')
-    ci, cj = ci.ravel(), cj.ravel()
-    V1, V2, V3, V4 = ci + Mx * cj, ci + 1 + Mx * cj, ci + 1 + Mx * (cj + 1), ci + Mx * (cj + 1)
-    if t is LagrangeElementType.P1:
-        elem = np.array((V1, V2, V4, V2, V3, V4)).reshape((3, 2 * ci.size), order='F')
-    else:
-        elem = np.array((V1, V2, V3, V4))
-    footing = np.logical_and(coord[1, :] == size_y, coord[0, :] <= 1.0001)
-    dirichlet = np.zeros(coord.shape)
-    dirichlet[1, footing] = 1
-    Q = coord > 0
-    Q[1, footing] = 0
-    Q[0, coord[0, :] == size_x] = 0
-    return {'coordinates': coord, 'elements': elem.astype(np.int64), 'surface': None,
-            'dirichlet_nodes': dirichlet, 'Q': Q}
+    """Same numbering on an n_x by n_y cell rectangle [0,size_x]x[0,size_y] (all four structured element types); used for
+    the multi-GPU strips of the benchmark.  Boundary masks follow DP:178-184 with the footing on the top edge
+    y == size_y and rollers on x == size_x.  The square n_x == n_y, size_x == size_y is the reference's mesh."""
+    return _rect(int(n_x), int(n_y), _coerce(element_type), size_x, size_y)
 
 
-def _square(N, t, size_xy):
-    ci, cj = np.meshgrid(np.arange(N), np.arange(N), indexing='xy')    # cell (i,j), j outer
+def _rect(Nx, Ny, t, size_x, size_y):
+    ci, cj = np.meshgrid(np.arange(Nx), np.arange(Ny), indexing='xy')    # cell (i,j), j outer
     ci = ci.ravel()
     cj = cj.ravel()
+    kx, ky = np.arange(Nx), np.arange(Ny)
     if t in (LagrangeElementType.P1, LagrangeElementType.Q1):
-        M = N + 1
-        xs = np.linspace(0, size_xy, M)
-        coord = np.array([np.tile(xs, M), np.repeat(xs, M)])
+        Mx, My = Nx + 1, Ny + 1
+        xs, ys = np.linspace(0, size_x, Mx), np.linspace(0, size_y, My)
+        coord = np.array([np.tile(xs, My), np.repeat(ys, Mx)])
 
         def nid(i, j):
-            return i + M * j
+            return i + Mx * j
         V1, V2, V3, V4 = nid(ci, cj), nid(ci + 1, cj), nid(ci + 1, cj + 1), nid(ci, cj + 1)
         if t is LagrangeElementType.P1:
-            elem = np.array((V1, V2, V4, V2, V3, V4)).reshape((3, 2 * N * N), order='F')
+            elem = np.array((V1, V2, V4, V2, V3, V4)).reshape((3, 2 * Nx * Ny), order='F')
         else:
             elem = np.array((V1, V2, V3, V4))
-        k = np.arange(N)
-        surf = np.concatenate((np.array((nid(k, 0), nid(k + 1, 0))), np.array((nid(N, k), nid(N, k + 1))),
-                               np.array((nid(k, N), nid(k + 1, N))), np.array((nid(0, k), nid(0, k + 1)))), axis=1)
+        surf = np.concatenate((np.array((nid(kx, 0), nid(kx + 1, 0))), np.array((nid(Nx, ky), nid(Nx, ky + 1))),
+                               np.array((nid(kx, Ny), nid(kx + 1, Ny))), np.array((nid(0, ky), nid(0, ky + 1)))), axis=1)
     elif t in (LagrangeElementType.P2, LagrangeElementType.Q2):
-        M = 2 * N + 1
-        xs = np.linspace(0, size_xy, M)
+        Mx, My = 2 * Nx + 1, 2 * Ny + 1
+        xs, ys = np.linspace(0, size_x, Mx), np.linspace(0, size_y, My)
         if t is LagrangeElementType.P2:
-            coord = np.array([np.tile(xs, M), np.repeat(xs, M)])
+            coord = np.array([np.tile(xs, My), np.repeat(ys, Mx)])
 
             def nid(i, j):
-                return i + M * j
+                return i + Mx * j
         else:
-            gi, gj = np.meshgrid(np.arange(M), np.arange(M), indexing='xy')
+            gi, gj = np.meshgrid(np.arange(Mx), np.arange(My), indexing='xy')
             keep = np.logical_not(np.logical_and(gi % 2 == 1, gj % 2 == 1))
-            coord = np.array([xs[gi[keep]], xs[gj[keep]]])
+            coord = np.array([xs[gi[keep]], ys[gj[keep]]])
 
             def nid(i, j):
-                # full rows (j even) hold M nodes, odd rows only the N+1 even-i nodes
-                before = ((j + 1) // 2) * M + (j // 2) * (N + 1)
+                # full rows (j even) hold Mx nodes, odd rows only the Nx+1 even-i nodes
+                before = ((j + 1) // 2) * Mx + (j // 2) * (Nx + 1)
                 return before + np.where(j % 2 == 0, i, i // 2)
         i2, j2 = 2 * ci, 2 * cj
         V1, V2, V3, V4 = nid(i2, j2), nid(i2 + 2, j2), nid(i2 + 2, j2 + 2), nid(i2, j2 + 2)
         V12, V14, V23, V34 = nid(i2 + 1, j2), nid(i2, j2 + 1), nid(i2 + 2, j2 + 1), nid(i2 + 1, j2 + 2)
         if t is LagrangeElementType.P2:
             V24 = nid(i2 + 1, j2 + 1)
-            elem = np.array((V1, V2, V4, V24, V14, V12, V2, V3, V4, V34, V24, V23)).reshape((6, 2 * N * N), order='F')
+            elem = np.array((V1, V2, V4, V24, V14, V12, V2, V3, V4, V34, V24, V23)).reshape((6, 2 * Nx * Ny), order='F')
         else:
             elem = np.array((V1, V2, V3, V4, V12, V23, V34, V14))
-        k = 2 * np.arange(N)
-        z = np.zeros(N, dtype=np.int64)
-        top = z + 2 * N
-        surf = np.concatenate((np.array((nid(k, z), nid(k + 2, z), nid(k + 1, z))),
-                               np.array((nid(top, k), nid(top, k + 2), nid(top, k + 1))),
-                               np.array((nid(k, top), nid(k + 2, top), nid(k + 1, top))),
-                               np.array((nid(z, k), nid(z, k + 2), nid(z, k + 1)))), axis=1)
+        ax, ay = 2 * kx, 2 * ky
+        zx, zy = np.zeros(Nx, dtype=np.int64), np.zeros(Ny, dtype=np.int64)
+        topx, topy = zy + 2 * Nx, zx + 2 * Ny
+        surf = np.concatenate((np.array((nid(ax, zx), nid(ax + 2, zx), nid(ax + 1, zx))),
+                               np.array((nid(topx, ay), nid(topx, ay + 2), nid(topx, ay + 1))),
+                               np.array((nid(ax, topy), nid(ax + 2, topy), nid(ax + 1, topy))),
+                               np.array((nid(zy, ay), nid(zy, ay + 2), nid(zy, ay + 1)))), axis=1)
     else:
         raise ValueError(f'no structured generator for {t}')
-    dirichlet, Q = _boundary(coord, size_xy)
+    footing = np.logical_and(coord[1, :] == size_y, coord[0, :] <= 1.0001)          # DP:178-184
+    dirichlet = np.zeros(coord.shape)
+    dirichlet[1, footing] = 1
+    Q = coord > 0
+    Q[1, footing] = 0
+    Q[0, coord[0, :] == size_x] = 0
     return {'coordinates': coord, 'elements': elem.astype(np.int64), 'surface': surf,
             'dirichlet_nodes': dirichlet, 'Q': Q}
 

@@ -186,12 +186,13 @@ def _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing=None, pcg_forcing_ca
 
 def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, max_steps=None, zeta_max=1.0,
                         device=None, log=None, context_factory=None, linear_solver='direct', pcg_rtol=1e-11,
-                        keep_U=True, pcg_forcing=None, pcg_forcing_cap=1e-4, pcg_inexact_rtol=None):
+                        keep_U=True, pcg_forcing=None, pcg_forcing_cap=1e-4, pcg_inexact_rtol=None, _ops_factory=None):
     """Strip-footing benchmark of Plasticity2D_DP (DP:901-1131).  `level` as in the reference
     (N = size_xy * 2**level cells per side) or `n_cells` directly.  Returns a dict with the load history
     ('zeta', 'pressure'), the accepted displacements 'U' (list of (2,n_n)), final 'Ep', counters.
     `context_factory(elements, coordinates, dhatp1, dhatp2, wf)` may supply another object with MeshContext's
-    `set_materials / step / geometry / close` (the tests drive the same loop with their CPU checker that way)."""
+    `set_materials / step / geometry / close` (the tests drive the same loop with their CPU checker that way);
+    `_ops_factory` supplies the vector / solve operations (dist_newton.py runs this loop on an element-sharded mesh)."""
     t = _coerce(element_type)
     young, poisson, c0, phi = 1e7, 0.48, 450, np.pi / 9                                   # DP:910-933
     shear0 = young / (2 * (1 + poisson))
@@ -206,7 +207,7 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     ctx = (context_factory or (lambda *a: MeshContext(*a, device=device)))(elem, coord, d1, d2, wf)
     ctx.set_materials(shear0, bulk0, eta0, c_0)
     qf = Q.flatten(order='F')
-    ops = _make_ops(ctx, qf, linear_solver, pcg_rtol, pcg_forcing, pcg_forcing_cap, pcg_inexact_rtol)
+    ops = (_ops_factory or _make_ops)(ctx, qf, linear_solver, pcg_rtol, pcg_forcing, pcg_forcing_cap, pcg_inexact_rtol)
     K_elast = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                        # DP:977
     if linear_solver == 'amg':
         ops.setup_amg(K_elast, coord)

@@ -25,7 +25,9 @@ class Partition:
     global node id of local node i: `nodes[i]`.
     `iface_local` : local node ids that other ranks also touch,
     `iface_slot`  : their positions in the global, sorted list of all interface nodes
-                    (the layout of the exchanged vector, 2 DOFs per slot)."""
+                    (the layout of the exchanged vector, 2 DOFs per slot),
+    `mult`        : per local node the number of ranks that hold it (weights 1/mult make inner products of
+                    interface-consistent vectors global ones: dist_newton.py)."""
 
     def __init__(self, elements, n_n, rank, world):
         elements = np.asarray(elements)
@@ -43,6 +45,7 @@ class Partition:
         self.local_elements = np.searchsorted(mine, elements[:, self.lo:self.hi])
         iface_global = np.flatnonzero(touch > 1)
         is_iface = touch[mine] > 1
+        self.mult = touch[mine].astype(np.float64)                 # number of ranks that hold each local node
         self.n_iface = int(iface_global.size)
         self.iface_local = np.flatnonzero(is_iface)
         self.iface_slot = np.searchsorted(iface_global, mine[is_iface])

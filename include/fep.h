@@ -73,7 +73,9 @@ int fep_sync(int device_id, void* stream);
  * staged through a ring of pinned slots filled by copy threads (FEP_COPY_THREADS, default 8).  The Python layer
  * places every output array it hands to the caller (s, ds, ind_p, K data, F: DP:1044-1058) in such blocks. */
 int fep_host_alloc(void** ptr_h, int64_t bytes);
-int fep_host_free(void* ptr_h);
+int fep_host_free(void* ptr_h);     /* FEP_EINVAL for a pointer that is not a live block of the cache (e.g. freed twice) */
+/* Unpins and frees every cached (idle) block.  fep_host_alloc does this by itself, once, before it reports FEP_ENOMEM. */
+int fep_host_trim(void);
 
 /* ---- a2: return map, mesh-free (pointwise) --------------------------------------------
  * Replaces construct_constitutive_problem, DP:604-757 (e0_h == NULL) and TSX:990-1157

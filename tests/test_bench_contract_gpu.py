@@ -33,24 +33,41 @@ def test_single_gpu_line():
     assert j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 1 and j['dtype'] == 'f64' and j['vs_baseline'] is None
     assert j['unit'] == 'updates/s' and j['higher_is_better'] is True and j['data'] == 'synthetic'
     n = 2 * 96 * 96
-    assert j['config']['elements_per_gpu'] == n and 'BASELINE configs[3]' not in j['config']['workload']   # only at 708 cells
+    assert j['config']['points_per_gpu'] == n and 'BASELINE configs[3]' not in j['config']['workload']   # only at 708 cells
     assert abs(j['value'] - n * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']
     r = j['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert r['traffic'] is None and abs(r['algorithmic_bytes_per_launch'] - 537.0 * n) < 1e-6     # traffic only for the profiled size
     assert j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['cores'] == 1 and j['cpu_baseline']['value'] > 0
     assert 0 < j['config']['smooth_points'] and 0 < j['config']['apex_points']
+    # the cpu_baseline leg ran the checker on the very mesh and field of the GPU step: the line carries the comparison
+    assert j['parity_max_rel'] <= 1e-11 and j['parity_vs_oracle']['ind_p_mismatches'] == 0
 
 
-@pytest.mark.parametrize('scaling', ['weak', 'strong'])
-def test_two_ranks_started_by_bench_itself(scaling):
-    j = _run(['--gpus', '2', '--backend', 'gloo', '--cells', '96', '--steps', '3', '--warmup', '1', '--scaling', scaling],
-             env={'FEP_BENCH_SINGLE_DEVICE': '1'})
+def test_single_gpu_line_p2():
+    """--elem P2 (BASELINE configs[4]'s element type, element route): 7 points per element, 461.6 B per update."""
+    j = _run(['--elem', 'P2', '--cells', '48', '--steps', '3', '--warmup', '1', '--state', 'random'])
+    n_e = 2 * 48 * 48
+    assert j['config']['element_type'] == 'P2' and j['config']['points_per_gpu'] == 7 * n_e and j['config']['elements_total'] == n_e
+    assert abs(j['value'] - 7 * n_e * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']
+    assert abs(j['roofline']['algorithmic_bytes_per_launch'] - (201 + 96 + 8 * 144 / 7) * 7 * n_e) < 1e-3
+    assert 'fixup_kernel' in j['roofline']['kernels_ms'] and j['parity_max_rel'] <= 1e-11
+    c = j['config']
+    assert min(c['smooth_points'], c['apex_points'], c['points_per_gpu'] - c['smooth_points'] - c['apex_points']) > 0.1 * c['points_per_gpu']
+
+
+@pytest.mark.parametrize('scaling,et,cells', [('weak', 'P1', 96), ('strong', 'P1', 96), ('strong', 'P2', 48)])
+def test_two_ranks_started_by_bench_itself(scaling, et, cells):
+    """('strong', 'P2'): the documented configs[4] command at a small size — `--gpus 2 --elem P2 --cells 48 --scaling strong`."""
+    j = _run(['--gpus', '2', '--backend', 'gloo', '--elem', et, '--cells', str(cells), '--steps', '3', '--warmup', '1',
+              '--scaling', scaling], env={'FEP_BENCH_SINGLE_DEVICE': '1'})
     assert KEYS <= set(j) and j['n_gpus'] == 2 and j['scaling'] == scaling and 'cpu_baseline' not in j
-    n = 2 * 96 * 96
-    assert j['config']['elements_total'] == (n if scaling == 'strong' else 2 * n)
+    n_e = 2 * cells * cells
+    nq = {'P1': 1, 'P2': 7}[et]
+    assert j['config']['elements_total'] == (n_e if scaling == 'strong' else 2 * n_e) and j['config']['element_type'] == et
+    assert j['config']['points_total'] == nq * j['config']['elements_total']
     assert len(j['per_rank']) == 2 and j['exchange_ms'] > 0
     assert ('strong' in j) == (scaling == 'weak')
     if scaling == 'weak':
-        assert j['strong']['elements_total'] == n and sum(r['elements'] for r in j['strong']['per_rank']) == n
-    assert abs(j['value'] - j['config']['elements_total'] * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']
+        assert j['strong']['elements_total'] == nq * n_e and sum(r['points'] for r in j['strong']['per_rank']) == nq * n_e
+    assert abs(j['value'] - j['config']['points_total'] * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']

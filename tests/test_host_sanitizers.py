@@ -7,6 +7,7 @@ and driven on structured, Delaunay (row order and random numbering), tsx-tunnel 
 is checked against the mesh by fep_host::validate_p1_plan (all indices the kernels will form stay inside their
 tables / LDS regions, tiles partition the blocks, every element has one owner).  CPU only.
 """
+import importlib
 import os
 import shutil
 import subprocess
@@ -124,3 +125,41 @@ def test_random_meshes_through_the_plan_validator(fep, binaries, tmp_path):
         for segs in ('1', '2', '4'):
             res = subprocess.run([binaries['asan'], path, segs], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
             assert res.returncode == 0 and 'result ok' in res.stdout, (trial, segs, res.stdout[-2000:])
+
+
+@pytest.mark.parametrize('kind', ['asan', 'tsan'])
+def test_staging_classes_under_sanitizers(tmp_path, kind):
+    """fep_staging.h (pinned cache, copy-thread pool, per-device staging engine) against a host stand-in of its HIP calls
+    (tests/staging_san.cpp): two host threads through the process-wide pool, two engines, a copy that fails after a
+    device -> host chunk was parked (no pending destination may survive the failed call), double release, allocation
+    failure with idle blocks to give back."""
+    if shutil.which('g++') is None:
+        pytest.skip('g++ not available')
+    exe = str(tmp_path / f'staging_{kind}')
+    flags = {'asan': ['-fsanitize=address,undefined', '-fno-sanitize-recover=all'], 'tsan': ['-fsanitize=thread']}[kind]
+    res = subprocess.run(['g++', '-std=c++17', '-O1', '-g', '-pthread'] + flags + ['-o', exe, os.path.join(ROOT, 'tests', 'staging_san.cpp')],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    env = dict(os.environ, FEP_COPY_THREADS='6', ASAN_OPTIONS='detect_leaks=1', TSAN_OPTIONS='halt_on_error=1')
+    res = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and 'staging ok' in res.stdout, res.stdout[-3000:]
+    assert 'Sanitizer' not in res.stdout and 'runtime error' not in res.stdout, res.stdout[-3000:]
+
+
+def test_library_rebuilds_when_the_staging_header_changes(fep):
+    """build.needs_build() looks at every file the library is compiled from (fep_staging.h was missing)."""
+    import re
+    b = importlib.import_module('fem-elastoplasticity_amd.build')
+    csrc = os.path.join(ROOT, 'fem-elastoplasticity_amd', 'csrc')
+    included = set()
+    for src in b.SOURCES:
+        todo = [src]
+        while todo:
+            f = todo.pop()
+            for inc in re.findall(r'#include "([^"]+)"', open(os.path.join(csrc, f)).read()):
+                name = os.path.normpath(os.path.join(os.path.dirname(f), inc))
+                if name not in included and os.path.exists(os.path.join(csrc, name)):
+                    included.add(name)
+                    todo.append(name)
+    deps = {os.path.normpath(d) for d in b.DEPS}
+    assert included <= deps, sorted(included - deps)

@@ -95,6 +95,40 @@ def test_tsx_p1_driver_vs_reference_replay(fep):
     assert abs(h['displ'][-1] - (-0.0019794496707526746)) <= 1e-10 * 0.0019794496707526746     # SURVEY 8c pin
 
 
+@pytest.mark.parametrize('route', ['node', 'node_list', 'node2k', 'node_unpacked', 'coo'])
+def test_tsx_p1_mesh_one_step_on_every_table_variant(fep, monkeypatch, route):
+    """The call that aborted in round 2's first GPU run (gpurun_out/r2a: tsx-tunnel P1 mesh, 476 nodes, unstructured, tiles
+    kept as strips, through fep_step_host; profiles/r03_ablation.md): one host-array step on that mesh on every table
+    variant of the P1 path — run lists, element / node LISTS ('node_list'), two kernels, unpacked descriptors, the element
+    route — with the plan replayed against the mesh first (FEP_VALIDATE_PLAN), checked against the oracle.  Once per
+    variant, no repetition."""
+    from oracle import fep_oracle as orc
+    monkeypatch.setenv('FEP_P1_PATH', route)
+    monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
+    g = load_golden('tsx')
+    elem, coord = g['elem'], g['coord']
+    n = elem.shape[1]
+    rng = np.random.default_rng(3)
+    from conftest import dp_materials
+    sh, bu, eta, c = dp_materials(n)
+    x, y = coord                                                   # the tunnel mesh spans [-50, 50]^2
+    U = 1e-5 * np.array([y * (x / 10) + 0.5 * x * (y > 0), -0.6 * y * (x < 0) + 0.8 * y * (x >= 0)])
+    U += rng.normal(0, 5e-7, size=U.shape)                         # 148 smooth / 128 apex / 611 elastic points
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(sh, bu, eta, c)
+    r = ctx.step(U, np.zeros((4, n)), want=('s', 'ds', 'ind_p', 'K', 'F'))
+    r_kf = ctx.step(U, np.zeros((4, n)), want=('K', 'F'))
+    d1, d2, wf = fep.element_tables('P1')
+    K, B, w, iD, jD, D = orc.elastic_setup(elem, coord, sh, bu, d1, d2, wf)
+    E, cp, K_t, F = orc.hot_path(U, np.zeros((4, n)), dict(K_elast=K, B=B, D_elast=D, weight=w, iD=iD, jD=jD, shear=sh, bulk=bu,
+                                                          eta=eta, c=c))
+    assert min(cp['n_smooth'], cp['n_apex'], n - cp['n_smooth'] - cp['n_apex']) > 50 and np.array_equal(r['ind_p'], cp['ind_p'])
+    assert relerr(r['s'], cp['s']) <= 1e-13 and relerr(r['ds'], cp['ds']) <= 1e-13
+    assert np.abs((r['K'] - K_t).data).max() <= 1e-12 * np.abs(K_t.data).max() and relerr(r['F'], F) <= 1e-12
+    assert np.array_equal(r_kf['K'].data, r['K'].data) and np.array_equal(r_kf['F'], r['F'])
+    ctx.close()
+
+
 def test_tsx_p2_first_steps(fep):
     """P2 mesh (midpoints from the reference generator, fixture): elastic steps are linear in zeta."""
     g = load_golden('tsx')

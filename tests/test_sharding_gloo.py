@@ -46,14 +46,14 @@ def _local_oracle(orc, elem, coord, U, d1, d2, wf):
     return K_t, F, cp
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, t='P1'):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from oracle import fep_oracle as orc
-    fep, elem, coord, U, d1, d2, wf = _problem()
+    fep, elem, coord, U, d1, d2, wf = _problem(t)
     part = fep.Partition(elem, coord.shape[1], rank, world)
     K_r, F_r, _ = _local_oracle(orc, part.local_elements, coord[:, part.nodes], U[:, part.nodes], d1, d2, wf)
     F_partial = F_r.copy()
@@ -63,16 +63,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_interface_force_allreduce_gloo(world):
+@pytest.mark.parametrize('t,world', [('P1', 2), ('P1', 3), ('P2', 2)])
+def test_interface_force_allreduce_gloo(t, world):
+    """P2 (BASELINE configs[4]'s element type): a cut through a P2 mesh shares one row of vertex + midside nodes
+    (2 nx + 1 nodes) when it falls between two cell rows."""
     from oracle import fep_oracle as orc
-    fep, elem, coord, U, d1, d2, wf = _problem()
+    fep, elem, coord, U, d1, d2, wf = _problem(t)
     K_g, F_g, cp = _local_oracle(orc, elem, coord, U, d1, d2, wf)
     assert cp['n_smooth'] > 0 and cp['n_apex'] > 0
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, t)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -90,8 +92,9 @@ def test_interface_force_allreduce_gloo(world):
         F_sum[dofs] += F_partial
         K_sum[np.ix_(dofs, dofs)] += K_r.toarray()
         covered[nodes] += 1
-        assert n_iface == 7 * (world - 1) and n_mine in (7, 14)       # one node row (nx+1 = 7) per cut
-    assert (covered >= 1).all() and (covered > 1).sum() == 7 * (world - 1)
+        row = 7 if t == 'P1' else 13                                  # one node row per cut: nx+1 = 7 (P1), 2 nx+1 = 13 (P2)
+        assert n_iface == row * (world - 1) and n_mine in (row, 2 * row)
+    assert (covered >= 1).all() and (covered > 1).sum() == (7 if t == 'P1' else 13) * (world - 1)
     assert np.abs(F_sum - F_g).max() <= 1e-12 * np.abs(F_g).max()    # partial forces sum to the global one
     assert np.abs(K_sum - K_g.toarray()).max() <= 1e-12 * np.abs(K_g.toarray()).max()   # sub-assembled K
 

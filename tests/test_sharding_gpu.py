@@ -12,7 +12,7 @@ from conftest import dp_materials, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('t,nx,ny,world', [('P1', 40, 60, 2), ('P1', 30, 45, 3), ('Q1', 24, 36, 2)])
+@pytest.mark.parametrize('t,nx,ny,world', [('P1', 40, 60, 2), ('P1', 30, 45, 3), ('Q1', 24, 36, 2), ('P2', 20, 30, 2), ('P2', 14, 21, 3)])
 def test_shards_reproduce_global_step(fep, t, nx, ny, world):
     mesh = fep.rect_mesh(nx, ny, t, 10, 15)
     elem, coord = mesh['elements'], mesh['coordinates']
@@ -99,6 +99,68 @@ def test_step_dev_is_graph_capturable_and_device_resident(fep):
     ctx.close()
 
 
+def test_step_dev_refuses_to_allocate_inside_a_stream_capture(fep):
+    """An accepting call that asks for K without ds needs the internal ds scratch of the two-kernel route.  On a fresh P1
+    context that scratch does not exist yet: inside a stream capture the call is refused with FEP_ESTATE (no hipMalloc
+    under capture, the capture stays intact); outside it allocates, and the same call then captures and replays."""
+    import torch
+    mesh = fep.square_mesh(24, 'P1', 10)
+    elem, coord = mesh['elements'], mesh['coordinates']
+    n = elem.shape[1]
+    x, y = coord
+    U = np.array([2.5e-4 * y * (x / 10) + 1.2e-4 * x * (y > 5), -1.5e-4 * y * (x < 5) + 2.0e-4 * y * (x >= 5)])
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(*dp_materials(n))
+    dev = torch.device('cuda', 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    Ud = torch.from_numpy(np.ascontiguousarray(U.reshape(-1, order='F'))).to(dev)
+    Ep = torch.zeros((4, n), **f64); Kd = torch.zeros(ctx.nnz, **f64); F = torch.zeros(ctx.n_dof, **f64)
+
+    def launch():
+        ctx.step_dev(torch.cuda.current_stream().cuda_stream, Ud.data_ptr(), ep=Ep.data_ptr(), accept=True,
+                     k_data=Kd.data_ptr(), f_out=F.data_ptr())
+    g = torch.cuda.CUDAGraph()
+    refused = None
+    with torch.cuda.graph(g):
+        try:
+            launch()
+        except fep.FepError as e:
+            refused = e.code
+    assert refused == -6                                           # FEP_ESTATE
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launch()                                                   # outside a capture: allocates the scratch
+    torch.cuda.synchronize()
+    K1 = Kd.cpu().numpy().copy()
+    Ep.zero_()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        launch()
+    Kd.zero_(); Ep.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(Kd.cpu().numpy(), K1) and np.abs(K1).max() > 0
+    ctx.close()
+
+
+def test_pinned_blocks_double_free_and_trim(fep):
+    """fep_host_free of a pointer that is already back in the cache is refused (it used to be queued twice and handed to two
+    arrays); fep_host_trim gives the idle blocks back."""
+    import ctypes
+    l = fep.lib()
+    p = ctypes.c_void_p()
+    assert l.fep_host_alloc(ctypes.byref(p), 1 << 16) == 0 and p.value
+    assert l.fep_host_free(p) == 0
+    assert l.fep_host_free(p) == -1                                # FEP_EINVAL: released twice
+    q = ctypes.c_void_p()
+    assert l.fep_host_alloc(ctypes.byref(q), 1 << 16) == 0 and q.value == p.value     # the idle block again
+    assert l.fep_host_free(q) == 0 and l.fep_host_trim() == 0
+    assert l.fep_host_free(q) == -1                                # no longer a block of the cache
+    a = fep._lib.pinned_empty((3, 1000))
+    a[...] = 1.5
+    assert a.sum() == 4500.0
+
+
 def test_contexts_and_solvers_release_their_device_memory(fep):
     """Create / destroy cycles (all routes' tables, solver hierarchy) leave the device allocation where it was."""
     import torch
@@ -129,7 +191,7 @@ def test_contexts_and_solvers_release_their_device_memory(fep):
     assert used() - base <= 64 << 20         # allocator granularity, not a per-cycle leak (five cycles allocate ~0.5 GB)
 
 
-@pytest.mark.parametrize('t,world', [('P1', 2), ('Q1', 2)])
+@pytest.mark.parametrize('t,world', [('P1', 2), ('Q1', 2), ('P2', 2)])
 def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
     """The product's multi-GPU path with real processes: `world` fresh processes share cuda:0 (gloo rendezvous), each
     runs ShardedContext.step_dev + exchange_force_ (pack kernel -> all-reduce -> unpack kernel) on two streams with a
@@ -174,6 +236,6 @@ def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
         counts += d['counts']
         covered[d['nodes']] += 1
         assert int(d['n_iface']) == (covered > 1).sum() or r == 0
-    assert (covered >= 1).all() and (covered > 1).sum() == 41 * (world - 1)       # one node row per cut
+    assert (covered >= 1).all() and (covered > 1).sum() == (81 if t == 'P2' else 41) * (world - 1)       # one node row per cut
     assert tuple(counts) == (ref['n_smooth'], ref['n_apex'])
     assert np.abs((K_sum - ref['K']).data).max() <= 1e-12 * np.abs(ref['K'].data).max()
