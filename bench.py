@@ -458,6 +458,13 @@ def run(args):
                 if errs['ind_p_mismatches'] or line['parity_max_rel'] > 1e-11:      # reported, never fatal: the line is the product
                     print(f'[bench] parity against the oracle outside the stated tolerance: {errs}', file=sys.stderr)
         print(json.dumps(line), flush=True)
+        try:        # the box's clocks next to the line (stderr): runs of the same binary differ by ~10 % between boxes of the pool
+            smi = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                 text=True, timeout=20).stdout
+            keep = [l.strip() for l in smi.splitlines() if 'GPU[0]' in l and any(k in l for k in ('sclk', 'mclk', 'fclk', 'Power'))]
+            print('[bench] ' + ' | '.join(keep), file=sys.stderr)
+        except Exception as exc:                                        # rocm-smi missing or refused: the line stands
+            print(f'[bench] rocm-smi not available: {exc}', file=sys.stderr)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
