@@ -83,7 +83,8 @@ class FepError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    # FEP_LIB_PATH: another build of the same C ABI (in-session A/B of kernel versions, tools/r03_matrix.sh); never a fallback
+    return os.environ.get('FEP_LIB_PATH') or _build.LIB
 
 
 def lib():

@@ -535,7 +535,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         // round 3, patch form of the element route: recomputed geometry wins for P2 as well (same session, 1 M elements:
         // 0.754 vs 0.783 ms on a fast box, 0.888 vs 0.936 on a slow one); the COO form keeps the streamed dphi arrays for P2
         const char* gpth = std::getenv("FEP_GEN_PATH");
-        const bool coo_form = gpth && std::strcmp(gpth, "coo") == 0;
+        const bool coo_form = gpth ? std::strcmp(gpth, "coo") == 0 : elem_type == FEP_Q2;
         c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : (elem_type == FEP_Q1 || elem_type == FEP_Q2 || (elem_type == FEP_P2 && !coo_form));
     }
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
@@ -551,9 +551,13 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         case FEP_P4: elem_eb = c->elem_geo ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB; break;
     }
     if (!c->p1_node && !c->gn && r == FEP_OK) {
-        // element route, default: the patch form (no K_e round trip through HBM); FEP_GEN_PATH=coo keeps the COO form
+        // element route: the patch form (no K_e round trip through HBM) or the COO form (FEP_GEN_PATH=patch | coo).  Default by
+        // what measured faster in one session at 0.25-4 M elements (profiles/r03_ablation.md): patch for P2 (-7 %, K,F-only -13 %,
+        // BASELINE configs[4] -8 %), Q1 (-10 %), P4 (-12 %) and P1; COO for Q2, whose patch form won at 250 k elements (-3 %) and
+        // lost at 500 k (+10 %) — its element kernel holds three workgroups per CU either way and pays most for phase 3
         const char* gp = std::getenv("FEP_GEN_PATH");
-        if (!(gp && std::strcmp(gp, "coo") == 0)) {
+        const bool want_patch = gp ? std::strcmp(gp, "coo") != 0 : elem_type != FEP_Q2;
+        if (want_patch) {
             fep_host::PatchPlan P;
             fep_host::PatchOptions popt;
             if (const char* po = std::getenv("FEP_PATCH_ORDER"))
