@@ -346,10 +346,14 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
     }
     if (pk_base != n_blk) return FEP_EINVAL;                                         // tiles partition the blocks
     if (!opt.allow_lds) return FEP_OK;
-    // per tile: blocks in tile order, sorted unique element list, local gather codes
+    // per tile: blocks in tile order, the staged elements, local gather codes.  The staged list holds the elements the tile
+    // OWNS first (the first tile in order that stages an element owns it: it alone writes the element's point outputs in
+    // the one-kernel step), ascending, then the others, ascending: the owner lanes of the one-kernel step are then lanes
+    // 0 .. n_own - 1 — whole waves store the point outputs instead of a scattered half of every wave.
     std::vector<std::vector<int32_t>> lists(n_wg);
     std::vector<std::vector<uint16_t>> codes(n_wg);
     std::vector<uint8_t> too_big((size_t)n_wg, 0);
+    std::vector<int32_t> n_own((size_t)n_wg, 0);
     parallel_chunks(n_wg, [&](int64_t lo, int64_t hi, int) {
         for (int64_t g = lo; g < hi; ++g) {
             const Tile& t = tiles[g];
@@ -358,18 +362,45 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
                 for (int32_t c = S.segptr[t.fb[s]]; c < S.segptr[t.fb[s] + t.nb[s]]; ++c) l.push_back(P.perm2[c] >> 4);
             std::sort(l.begin(), l.end());
             l.erase(std::unique(l.begin(), l.end()), l.end());
-            if (l.size() > 4095) { too_big[g] = 1; continue; }
+            if (l.size() > 4095) too_big[g] = 1;
+        }
+    });
+    for (int64_t g = 0; g < n_wg; ++g)
+        if (too_big[g]) return FEP_OK;                                               // plan without the LDS route
+    {   // owners, in tile order (sequential), then every list: owned elements first
+        std::vector<uint8_t> owned((size_t)n_e, 0);
+        std::vector<int32_t> rest;
+        for (int64_t g = 0; g < n_wg; ++g) {
+            std::vector<int32_t>& l = lists[g];
+            rest.clear();
+            size_t k = 0;
+            for (size_t i = 0; i < l.size(); ++i) {
+                const int32_t e = l[i];
+                if (!owned[e]) { owned[e] = 1; l[k++] = e; } else rest.push_back(e);
+            }
+            n_own[g] = (int32_t)k;
+            std::copy(rest.begin(), rest.end(), l.begin() + (int64_t)k);
+        }
+    }
+    parallel_chunks(n_wg, [&](int64_t lo, int64_t hi, int) {
+        std::vector<std::pair<int32_t, int32_t>> where;                              // (element, slot), sorted by element
+        for (int64_t g = lo; g < hi; ++g) {
+            const Tile& t = tiles[g];
+            const std::vector<int32_t>& l = lists[g];
+            where.clear();
+            for (size_t i = 0; i < l.size(); ++i) where.emplace_back(l[i], (int32_t)i);
+            std::sort(where.begin(), where.end());
             std::vector<uint16_t>& cd = codes[g];
             for (int s = 0; s < t.nseg; ++s)
                 for (int32_t c = S.segptr[t.fb[s]]; c < S.segptr[t.fb[s] + t.nb[s]]; ++c) {
-                    const int32_t loc = (int32_t)(std::lower_bound(l.begin(), l.end(), P.perm2[c] >> 4) - l.begin());
+                    const int32_t e = P.perm2[c] >> 4;
+                    const int32_t loc = std::lower_bound(where.begin(), where.end(), std::make_pair(e, (int32_t)0))->second;
                     cd.push_back((uint16_t)((loc << 4) | (P.perm2[c] & 15)));
                 }
         }
     });
     size_t lmax = 0, cmax = 0;
     for (int64_t g = 0; g < n_wg; ++g) {
-        if (too_big[g]) return FEP_OK;                                               // plan without the LDS route
         lmax = std::max(lmax, lists[g].size());
         cmax = std::max(cmax, codes[g].size());
         P.staged_total += (int64_t)lists[g].size();
@@ -472,13 +503,9 @@ inline int build_p1_plan_segs(const Symbolic& S, int64_t n_e, int64_t n_n, const
         P.staged_nodes_total += (int64_t)nlists[g].size();
     }
     if (nlmax == 0 || nlmax > (size_t)TILE) { P.elnodes.clear(); return FEP_OK; }
-    {   // owner bits, in tile order
-        std::vector<uint8_t> owned((size_t)n_e, 0);
-        for (int64_t g = 0; g < n_wg; ++g)
-            for (size_t i = 0; i < lists[g].size(); ++i) {
-                const int32_t e = lists[g][i];
-                if (!owned[e]) { owned[e] = 1; P.elnodes[(size_t)(g * LP) + i] |= 1u << 30; }
-            }
+    for (int64_t g = 0; g < n_wg; ++g) {                                             // owner bit = slot < n_own; the count rides in the descriptor
+        for (int32_t i = 0; i < n_own[g]; ++i) P.elnodes[(size_t)(g * LP) + i] |= 1u << 30;
+        P.tdesc[(size_t)g * kDescInts + 2] |= n_own[g] << 8;
     }
     const int64_t NLP = (int64_t)((nlmax + 1) & ~(size_t)1);
     P.NL = (int)NLP;
@@ -524,7 +551,8 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
     for (int64_t g = 0; g < P.n_wg; ++g) {
         const int32_t* d = P.tdesc.data() + g * kDescInts;
         const int nseg = d[3] & 15, n_staged = (d[3] >> 4) & 4095, n_staged_nodes = (d[3] >> 16) & 4095;
-        if (d[0] != pk_base || nseg < 1 || nseg > kSegMax || d[1] > P.tile || d[1] < 1 || d[2] > 255) return 2;
+        const int nn_desc = d[2] & 255, n_own = d[2] >> 8;                           // (n_own is packed in only by the one-kernel plan)
+        if (d[0] != pk_base || nseg < 1 || nseg > kSegMax || d[1] > P.tile || d[1] < 1 || n_own > n_staged) return 2;
         int nb = 0, nn = 0;
         for (int s = 0; s < nseg; ++s) {
             const int32_t fb = d[4 + 4 * s], sb = d[5 + 4 * s], fn = d[6 + 4 * s], sn = d[7 + 4 * s];
@@ -532,16 +560,24 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
             for (int32_t b = fb; b < fb + sb; ++b) { if (seen[b]) return 4; seen[b] = 1; }
             nb += sb; nn += sn;
         }
-        if (nb != d[1] || nn != d[2]) return 5;
+        if (nb != d[1] || nn != nn_desc) return 5;
         pk_base += nb;
         if (!P.lds) continue;
         const int32_t* el = P.elist_pad.data() + g * P.L;
-        int n_list = 1;
+        const int n_list = n_staged;
+        if (n_list < 1 || n_list > P.L) return 18;
         for (int i = 0; i < P.L; ++i) {
             if (el[i] < 0 || el[i] >= n_e) return 6;
-            if (i > 0 && el[i] > el[i - 1]) n_list = i + 1;
+            if (i >= n_list && el[i] != el[0]) return 18;                            // padding repeats the first element
         }
-        if (n_list != n_staged) return 18;
+        {   // distinct; with the one-kernel plan: owned elements first, each part ascending
+            std::vector<int32_t> srt(el, el + n_list);
+            std::sort(srt.begin(), srt.end());
+            if (std::adjacent_find(srt.begin(), srt.end()) != srt.end()) return 18;
+            if (P.fused)
+                for (int i = 1; i < n_list; ++i)
+                    if (i != n_own && el[i] <= el[i - 1]) return 18;
+        }
         if (P.rng) {
             const int32_t* r = P.rng_tab.data() + g * 16;
             for (int i = 0; i < P.L; ++i) {
@@ -590,7 +626,8 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
                     const int loc = (int)((w >> (10 * a)) & 1023u);
                     if (loc >= P.NL || nl[loc] != elem[(int64_t)a * n_e + el[i]]) return 13;
                 }
-                if ((w >> 30) & 1u) { if (i >= n_list) return 14; owners[el[i]]++; }
+                if (((w >> 30) & 1u) != (i < n_own ? 1u : 0u)) return 14;                  // owner bit <=> slot < n_own
+                if (i < n_own) owners[el[i]]++;
             }
         }
     }

@@ -950,14 +950,14 @@ __device__ __forceinline__ void glds4(const void* g, void* wave_base) {
 static_assert(kSegMax == 4, "the tile descriptor names its four segments");
 // plain ints (no HIP vector types, no arrays): the descriptor stays in scalar registers
 struct TileDesc {
-    int pk_base, nb, nn, nseg, n_el, n_nd;              // n_el / n_nd: staged elements / nodes of THIS tile (<= L / NL)
+    int pk_base, nb, nn, nseg, n_el, n_nd, n_own;       // n_el / n_nd: staged elements / nodes of THIS tile (<= L / NL); the first n_own staged elements are the tile's own
     int fb0, nb0, fn0, nn0, fb1, nb1, fn1, nn1, fb2, nb2, fn2, nn2, fb3, nb3, fn3, nn3;
 };
 
 __device__ __forceinline__ TileDesc load_tile_desc(const int4* __restrict__ tdesc, int wg) {
     const int32_t* d = reinterpret_cast<const int32_t*>(tdesc) + (int64_t)wg * 4 * (1 + kSegMax);   // uniform address: scalar loads
     TileDesc t;
-    t.pk_base = d[0]; t.nb = d[1]; t.nn = d[2]; t.nseg = d[3] & 15; t.n_el = (d[3] >> 4) & 4095; t.n_nd = (d[3] >> 16) & 4095;
+    t.pk_base = d[0]; t.nb = d[1]; t.nn = d[2] & 255; t.n_own = d[2] >> 8; t.nseg = d[3] & 15; t.n_el = (d[3] >> 4) & 4095; t.n_nd = (d[3] >> 16) & 4095;
     t.fb0 = d[4]; t.nb0 = d[5]; t.fn0 = d[6]; t.nn0 = d[7];
     t.fb1 = d[8]; t.nb1 = d[9]; t.fn1 = d[10]; t.nn1 = d[11];
     t.fb2 = d[12]; t.nb2 = d[13]; t.fn2 = d[14]; t.nn2 = d[15];
@@ -1335,7 +1335,7 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
         if (i < n_el) {
             const uint32_t wv = enw[r];
             const int64_t e = el[r];
-            own = (wv >> 30) & 1u;
+            own = i < td.n_own;                          // the tile's own elements come first in its staged list
             const int i0 = (int)(wv & 1023u), i1 = (int)((wv >> 10) & 1023u), i2 = (int)((wv >> 20) & 1023u);
             const double2 c0 = lxy[i0], c1 = lxy[i1], c2 = lxy[i2];
             double d1[3], d2[3], w;
@@ -1355,7 +1355,8 @@ p1_fused_kernel(int64_t n_e, int L, int C, int NL,
                 const double m_sh = mu.on ? mu.shear : mv[r][0], m_bu = mu.on ? mu.bulk : mv[r][1];
                 const double m_eta = mu.on ? mu.eta : mv[r][2], m_c = mu.on ? mu.c : mv[r][3];
                 branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, false, s, d);
-                if (FULL && own) {
+                // (wave-uniform first: the waves past the tile's own elements issue none of the 14-17 store instructions)
+                if (FULL && r * TPB + (int)(threadIdx.x & ~63u) < td.n_own && own) {
                     store_point(e, n_e, s, d, branch, S, DS, indp);
                     if (Eout) { Eout[e] = ev[0]; Eout[n_e + e] = ev[1]; Eout[2 * n_e + e] = ev[2]; }
                 }

@@ -1,6 +1,6 @@
 """
 One rank of the distributed Newton test (tests/test_solver_gpu.py::test_sharded_newton_two_processes_vs_reference_trace):
-`python tests/dist_newton_worker.py RANK WORLD PORT OUTDIR [ELEMENT_TYPE]`, every rank on cuda:0, gloo rendezvous on
+`python tests/dist_newton_worker.py RANK WORLD PORT OUTDIR [MAX_STEPS]`, every rank on cuda:0, gloo rendezvous on
 127.0.0.1.  Runs Plasticity2D_DP's load-step loop at level 1 on the element-sharded mesh (dist_newton.py: hot path per
 shard, interface exchange, distributed conjugate gradients on the sub-assembled K) and writes the history to
 OUTDIR/rank<r>.npz.
@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    t = sys.argv[5] if len(sys.argv) > 5 else 'P1'
+    t = 'P1'
+    max_steps = int(sys.argv[5]) if len(sys.argv) > 5 and int(sys.argv[5]) > 0 else None
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
@@ -25,7 +26,7 @@ def main():
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     fep = importlib.import_module('fem-elastoplasticity_amd')
-    h = fep.solve_strip_footing_sharded(t, level=1, device=0)
+    h = fep.solve_strip_footing_sharded(t, level=1, device=0, max_steps=max_steps)
     np.savez(os.path.join(outdir, f'rank{rank}.npz'), zeta=np.array(h['zeta']), pressure=np.array(h['pressure']),
              U=np.array(h['U']), n_calls=np.array(h['n_calls']), counts=np.array(h['counts']),
              pcg_iters=np.array(h['pcg_iters']), n_local_points=np.array(h['Ep'].shape[1]))

@@ -232,13 +232,14 @@ def test_sharded_newton_single_process_reproduces_reference_trace(fep):
     assert h['counts'][-1] == (599, 171)
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_newton_processes_vs_reference_trace(fep, tmp_path, world):
+@pytest.mark.parametrize('world,n_steps', [(2, 16), (3, 6)])
+def test_sharded_newton_processes_vs_reference_trace(fep, tmp_path, world, n_steps):
     """BASELINE configs[3] as written ("... 1 vs 2 vs 4 vs 8 GPUs") end to end at the size the reference itself can run:
     `world` processes (here all on cuda:0, gloo), each with its element shard — iterate, K_r, F, plastic strain stay on
     the rank; hot path per shard + interface-force exchange; distributed block-Jacobi conjugate gradients on the
     sub-assembled K (local block SpMV + the same exchange + two scalar all-reduces per iteration).  Every rank must
-    reproduce the reference driver's level-1 trace: load history exact, pressures 1e-8, accepted displacements 1e-9."""
+    reproduce the reference driver's level-1 trace: load history exact, pressures 1e-8, accepted displacements 1e-9 (two
+    ranks: all 16 load steps; three ranks — an interior shard with two cuts — the first six, to keep the suite short)."""
     import os
     import socket
     import subprocess
@@ -251,7 +252,7 @@ def test_sharded_newton_processes_vs_reference_trace(fep, tmp_path, world):
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist_newton_worker.py')
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path)], env=env,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path), str(n_steps if n_steps < 16 else 0)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     for p in procs:
         out, _ = p.communicate(timeout=900)
@@ -259,11 +260,13 @@ def test_sharded_newton_processes_vs_reference_trace(fep, tmp_path, world):
     n_pts = 0
     for r in range(world):
         d = np.load(tmp_path / f'rank{r}.npz')
-        assert len(d['zeta']) == 16 and np.allclose(d['zeta'], g['zeta'], rtol=0, atol=1e-15)
-        assert np.abs(d['pressure'][:15] - g['pressure'][1:16]).max() <= 1e-8 * np.abs(g['pressure']).max()
-        for k in range(16):
+        assert len(d['zeta']) == n_steps and np.allclose(d['zeta'], g['zeta'][:n_steps], rtol=0, atol=1e-15)
+        assert np.abs(d['pressure'][:n_steps - 1] - g['pressure'][1:n_steps]).max() <= 1e-8 * np.abs(g['pressure']).max()
+        for k in range(n_steps):
             assert relerr(d['U'][k], g['U_accepted'][k]) <= 1e-9, (r, k)
-        assert tuple(d['counts'][-1]) == (599, 171)                   # global counts on every rank
+        # global branch counts on every rank: the reference's own (smooth, apex) pair of that accepting call
+        assert (g['counts'] == d['counts'][-1]).all(axis=1).any() and (n_steps < 16 or tuple(d['counts'][-1]) == (599, 171))
+        assert np.array_equal(d['counts'], np.load(tmp_path / 'rank0.npz')['counts'])
         assert int(d['n_calls']) == int(np.load(tmp_path / 'rank0.npz')['n_calls'])
         n_pts += int(d['n_local_points'])
     assert n_pts == 800                                              # 20 x 20 cells x 2 triangles, every point on one rank
