@@ -32,7 +32,7 @@ struct fep_ctx {
     bool kc_aos = false;                                // K_e half-blocks: all blocks of an element adjacent (AoS) or block-major (SoA)
     // patch route of the element kernel (default; FEP_GEN_PATH=coo keeps the K_e round trip): fep_host.h, PatchPlan
     bool patch = false;
-    int patch_eb = 0, patch_dbg = 0;
+    int patch_eb = 0, patch_dbg = 0, patch_tpb = 256;   // FEP_PATCH_TPB=512 (P2): patches of twice the elements, 512-thread workgroups
     int lds_pad = 0;                                    // FEP_ELEM_LDS_PAD: extra LDS bytes per workgroup of element_kernel (occupancy experiments)
     int64_t n_open = 0, n_fopen = 0;
     int32_t *pt_desc = nullptr, *pt_plist = nullptr, *pt_pel = nullptr, *pt_pnodes = nullptr;
@@ -543,20 +543,22 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
     if (const char* lp = std::getenv("FEP_ELEM_LDS_PAD")) c->lds_pad = std::max(0, std::atoi(lp));
     int elem_eb = 1;
+    // element route: the patch form (no K_e round trip through HBM) or the COO form (FEP_GEN_PATH=patch | coo).  Default by
+    // what measured faster in one session at 0.25-4 M elements (profiles/r03_ablation.md): patch for P2 (-7 %, K,F-only -13 %,
+    // BASELINE configs[4] -8 %), Q1 (-10 %), P4 (-12 %) and P1; COO for Q2, whose patch form won at 250 k elements (-3 %) and
+    // lost at 500 k (+10 %) — its element kernel holds three workgroups per CU either way and pays most for phase 3
+    const char* gen_path = std::getenv("FEP_GEN_PATH");
+    const bool want_patch = !c->p1_node && !c->gn && (gen_path ? std::strcmp(gen_path, "coo") != 0 : elem_type != FEP_Q2);
+    if (const char* tp = std::getenv("FEP_PATCH_TPB")) c->patch_tpb = (want_patch && std::atoi(tp) == 512 && elem_type == FEP_P2) ? 512 : 256;
     switch (elem_type) {
         case FEP_P1: elem_eb = c->elem_geo ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB; break;
-        case FEP_P2: elem_eb = c->elem_geo ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB; break;
+        case FEP_P2: elem_eb = c->patch_tpb == 512 ? (c->elem_geo ? ElemCfg<6, 7, true, 512>::EB : ElemCfg<6, 7, false, 512>::EB)
+                                                  : (c->elem_geo ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB); break;
         case FEP_Q1: elem_eb = c->elem_geo ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB; break;
         case FEP_Q2: elem_eb = c->elem_geo ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB; break;
         case FEP_P4: elem_eb = c->elem_geo ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB; break;
     }
     if (!c->p1_node && !c->gn && r == FEP_OK) {
-        // element route: the patch form (no K_e round trip through HBM) or the COO form (FEP_GEN_PATH=patch | coo).  Default by
-        // what measured faster in one session at 0.25-4 M elements (profiles/r03_ablation.md): patch for P2 (-7 %, K,F-only -13 %,
-        // BASELINE configs[4] -8 %), Q1 (-10 %), P4 (-12 %) and P1; COO for Q2, whose patch form won at 250 k elements (-3 %) and
-        // lost at 500 k (+10 %) — its element kernel holds three workgroups per CU either way and pays most for phase 3
-        const char* gp = std::getenv("FEP_GEN_PATH");
-        const bool want_patch = gp ? std::strcmp(gp, "coo") != 0 : elem_type != FEP_Q2;
         if (want_patch) {
             fep_host::PatchPlan P;
             fep_host::PatchOptions popt;
@@ -600,6 +602,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         }
         c->n_count_blocks = c->patch ? (int)c->n_patch : (int)grid_for(n_e, elem_eb);
     }
+    if (!c->patch && c->patch_tpb != 256) r = r == FEP_OK ? FEP_ESTATE : r;        // (a 512-thread plan that could not be built: no silent change of patch size)
     if (!c->patch) {
         CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
         CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
@@ -740,23 +743,31 @@ template <int NP, int NQ, bool FROM_U>
 static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept,
                           double* eout, double* s, double* ds, uint8_t* indp, uint2* blk_counts,
                           double* Kc, double* fe) {
-    static_assert(ElemCfg<NP, NQ, false>::EB * (NQ > NP ? NQ : NP) <= kBlock, "one pass per phase");
     // patch route: Kc / fe carry the caller's CSR values / force (phase 3 writes them, fixup_kernel the open rest)
     const PatchArgs pa{c->pt_desc, c->pt_pel, c->pt_pnodes, c->pt_items, c->pt_codes, c->pt_fitems, c->pt_fcodes, c->Pc, c->Pf,
                        c->patch ? Kc : nullptr, c->patch ? fe : nullptr, c->patch_dbg};
-#define ELEM_LAUNCH(GEO, PATCH)                                                                                          \
+#define ELEM_LAUNCH(GEO, PATCH) ELEM_LAUNCH_T(GEO, PATCH, kBlock)
+#define ELEM_LAUNCH_T(GEO, PATCH, TPB)                                                                                   \
     do {                                                                                                                 \
-        if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO>::EB) return FEP_ESTATE;                             \
-        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH>),                                                \
-                           dim3(PATCH ? (unsigned)c->n_patch : grid_for(c->n_e, ElemCfg<NP, NQ, GEO>::EB)),                \
-                           dim3(kBlock), (size_t)c->lds_pad, st, c->n_e,                                                \
+        if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO, TPB>::EB) return FEP_ESTATE;                        \
+        if (sizeof(double) * ElemCfg<NP, NQ, GEO, TPB>::kPts > 64 * 1024)                                                \
+            (void)0;                                                                                                     \
+        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB>),                                           \
+                           dim3(PATCH ? (unsigned)c->n_patch : grid_for(c->n_e, ElemCfg<NP, NQ, GEO, TPB>::EB)),           \
+                           dim3(TPB), (size_t)c->lds_pad, st, c->n_e,                                                   \
                            c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,   \
                            c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts,                       \
                            PATCH ? nullptr : Kc, PATCH ? nullptr : fe, c->kc_aos ? 1 : 0, pa);                          \
     } while (0)
-    if (c->patch) { if (c->elem_geo) ELEM_LAUNCH(true, true); else ELEM_LAUNCH(false, true); }
+    if (c->patch && c->patch_tpb == 512) {
+        // (P2 only: the one element type the 512-thread patch has been measured on)
+        if constexpr (NP == 6 && NQ == 7) { if (c->elem_geo) ELEM_LAUNCH_T(true, true, 512); else ELEM_LAUNCH_T(false, true, 512); }
+        else return FEP_ESTATE;
+    }
+    else if (c->patch) { if (c->elem_geo) ELEM_LAUNCH(true, true); else ELEM_LAUNCH(false, true); }
     else { if (c->elem_geo) ELEM_LAUNCH(true, false); else ELEM_LAUNCH(false, false); }
 #undef ELEM_LAUNCH
+#undef ELEM_LAUNCH_T
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }

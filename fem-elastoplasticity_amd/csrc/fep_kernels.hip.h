@@ -292,13 +292,17 @@ inline __host__ __device__ void sym_block_index(int n_p, int a, int b, int& idx,
 }
 inline __host__ __device__ int sym_block_count(int n_p) { return (n_p / 2 + 1) * n_p; }   // upper bound on idx + 1
 
-template <int NP, int NQ, bool GEO = false> struct ElemCfg {
+template <int NP, int NQ, bool GEO = false, int TPB = kBlock> struct ElemCfg {
     static constexpr int maxpq = NP > NQ ? NP : NQ;
-    static constexpr int EB0 = (kBlock / maxpq) >= 64 ? 64 : ((kBlock / maxpq) >= 32 ? 32 : (kBlock / maxpq));
+    static constexpr int EB0 = (TPB / maxpq) >= TPB / 4 ? TPB / 4 : ((TPB / maxpq) >= TPB / 8 ? TPB / 8 : (TPB / maxpq));
     // with the coordinate staging of GEO the big elements take fewer per workgroup, so that the LDS still admits
     // as many resident workgroups as without it (P2: 4 per CU, Q2: 3)
     // (the 15-node element: 16 instead of 17, so that two workgroups with their gather codes fit a CU's LDS)
-    static constexpr int EB = NP == 15 ? 16 : !GEO ? EB0 : (NP == 6 && NQ == 7) ? 28 : (NP == 8 && NQ == 9) ? 24 : EB0;
+    // TPB = 512 (patch form, FEP_PATCH_TPB=512): twice the elements per workgroup — a patch four runs high with runs as long
+    // as before — at the same waves per CU (two workgroups of eight waves)
+    static constexpr int S = TPB / kBlock;
+    static constexpr int EB = NP == 15 ? 16 * S : !GEO ? (NP == 6 && NQ == 7 && S == 2 ? 60 : EB0)
+                                                       : (NP == 6 && NQ == 7) ? 28 * S : (NP == 8 && NQ == 9) ? 24 * S : EB0;
     static constexpr int NQS = NQ | 1;                  // odd LDS stride: conflict-free ds_read_b64 over elements
     static constexpr int NPTS = EB * NQS;
     static constexpr int NJ = NP / 2 + 1;               // stored node-pair blocks (a, a+j mod NP) per local node
@@ -327,8 +331,8 @@ struct PatchArgs {
     int dbg;                                            // ablation switches (FEP_PATCH_DBG), 0 in production
 };
 
-template <int NP, int NQ, bool FROM_U, bool GEO, bool PATCH = false>
-__global__ void __launch_bounds__(kBlock)
+template <int NP, int NQ, bool FROM_U, bool GEO, bool PATCH = false, int TPB = kBlock>
+__global__ void __launch_bounds__(TPB)
 element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                const double* __restrict__ dphi1, const double* __restrict__ dphi2, const double* __restrict__ weight,
                // GEO: geometry recomputed from the coordinates (xy interleaved) and the reference-element tables
@@ -343,12 +347,12 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                uint2* blk_counts,
                // outputs of phase 2 (kc_aos: all stored blocks of an element adjacent, see sym_block_index)
                double* __restrict__ Kc, double* __restrict__ fe, int kc_aos, PatchArgs pa) {
-    using C = ElemCfg<NP, NQ, GEO>;
+    using C = ElemCfg<NP, NQ, GEO, TPB>;
     constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
     constexpr int NJ = C::NJ;                        // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
     constexpr int kP12 = C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2) + (GEO ? C::kTab : 4);
     constexpr int kLds = (PATCH && C::kPhase3 > kP12) ? C::kPhase3 : kP12;                  // phases 1-2 | phase 3, same memory
-    static_assert(EB * NQ <= kBlock && EB * NP <= kBlock, "one pass per phase");
+    static_assert(EB * NQ <= TPB && EB * NP <= TPB, "one pass per phase");
     __shared__ __attribute__((aligned(16))) double lds[kLds];
     double (*d1s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds);
     double (*d2s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + NP * NPTS);
@@ -382,13 +386,13 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             if (FROM_U) cu[a][el] = *reinterpret_cast<const double2*>(U + 2 * nd);
         }
         if (GEO) {
-            for (int i = t; i < NP * NQ; i += kBlock) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
-            for (int i = t; i < NQ; i += kBlock) tw[i] = wf[i];
+            for (int i = t; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+            for (int i = t; i < NQ; i += TPB) tw[i] = wf[i];
         }
     }
     if (FROM_U || GEO || PATCH) __syncthreads();
 
-    // ---- phase 1 (one pass: EB * NQ <= kBlock).  The point's operand loads are issued here, after the barrier: hoisting
+    // ---- phase 1 (one pass: EB * NQ <= TPB).  The point's operand loads are issued here, after the barrier: hoisting
     // them (and the patch tables) in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
     int branch = 0;
     const int el1 = t / NQ, q1 = t - el1 * NQ;
@@ -442,7 +446,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     if (FROM_U) count_branches(branch, nullptr, blk_counts);
     if (pa.dbg & 64) __syncthreads(); else lds_barrier();              // (the point outputs' stores drain behind phase 2)
 
-    // ---- phase 2 (one pass: NP * EB <= kBlock) ----------------------------------------
+    // ---- phase 2 (one pass: NP * EB <= TPB) ----------------------------------------
     double kk[NJ][4];
     double f0 = 0.0, f1 = 0.0;
     const int a = t / EB, el = t - a * EB;
@@ -498,16 +502,16 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     const uint2* its = pa.items + item_off;
     uint2 dsc[IT];
 #pragma unroll
-    for (int u = 0; u < IT; ++u) { const int it = u * kBlock + t; dsc[u] = (pa.data && it < n_items) ? its[it] : make_uint2(0u, 0u); }
-    constexpr int CWPT = (NP * NP * EB / 2 + kBlock) / kBlock, FWPT = (NP * EB / 2 + kBlock) / kBlock;
+    for (int u = 0; u < IT; ++u) { const int it = u * TPB + t; dsc[u] = (pa.data && it < n_items) ? its[it] : make_uint2(0u, 0u); }
+    constexpr int CWPT = (NP * NP * EB / 2 + TPB) / TPB, FWPT = (NP * EB / 2 + TPB) / TPB;
     uint32_t cpre[CWPT], fpre[FWPT];
     {   // two codes per 32-bit word (every patch's codes start at an even offset; one pad entry may be read)
         const uint32_t* cg = reinterpret_cast<const uint32_t*>(pa.codes + code_off);
         const uint32_t* fg = reinterpret_cast<const uint32_t*>(pa.fcodes + fcode_off);
 #pragma unroll
-        for (int r = 0; r < CWPT; ++r) { const int i = r * kBlock + t; cpre[r] = (pa.data && i < (n_codes + 1) / 2) ? cg[i] : 0u; }
+        for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; cpre[r] = (pa.data && i < (n_codes + 1) / 2) ? cg[i] : 0u; }
 #pragma unroll
-        for (int r = 0; r < FWPT; ++r) { const int i = r * kBlock + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
+        for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
     }
     if (pa.dbg & 64) __syncthreads(); else lds_barrier();              // every lane is done reading the phase-2 operands
     if (lane2) {
@@ -521,21 +525,21 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         fl2[a * EB + el] = make_double2(f0, f1);
     }
 #pragma unroll
-    for (int r = 0; r < CWPT; ++r) { const int i = r * kBlock + t; if (i < (n_codes + 1) / 2) codes32[i] = cpre[r]; }
+    for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; if (i < (n_codes + 1) / 2) codes32[i] = cpre[r]; }
 #pragma unroll
-    for (int r = 0; r < FWPT; ++r) { const int i = r * kBlock + t; if (i < (n_fcodes + 1) / 2) fcodes32[i] = fpre[r]; }
+    for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; if (i < (n_fcodes + 1) / 2) fcodes32[i] = fpre[r]; }
     if (pa.dbg & 64) __syncthreads(); else lds_barrier();
     if (pa.data && !(pa.dbg & 4)) {
         double2* data2 = reinterpret_cast<double2*>(pa.data);
         double2* Pc2 = reinterpret_cast<double2*>(pa.Pc);
-        for (int base = 0; base < n_items; base += IT * kBlock) {
+        for (int base = 0; base < n_items; base += IT * TPB) {
             if (base > 0) {
 #pragma unroll
-                for (int u = 0; u < IT; ++u) { const int it = base + u * kBlock + t; dsc[u] = it < n_items ? its[it] : make_uint2(0u, 0u); }
+                for (int u = 0; u < IT; ++u) { const int it = base + u * TPB + t; dsc[u] = it < n_items ? its[it] : make_uint2(0u, 0u); }
             }
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
-                if (base + u * kBlock + t >= n_items) continue;
+                if (base + u * TPB + t >= n_items) continue;
                 const uint32_t x = dsc[u].x, y = dsc[u].y;
                 const int off = (int)(x & 8191u), cnt = (int)((x >> 13) & 63u) + 1;
                 double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
@@ -562,7 +566,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     if (pa.F) {
         double2* F2 = reinterpret_cast<double2*>(pa.F);
         double2* Pf2 = reinterpret_cast<double2*>(pa.Pf);
-        for (int it = t; it < n_fitems; it += kBlock) {
+        for (int it = t; it < n_fitems; it += TPB) {
             const uint2 d = pa.fitems[fitem_off + it];
             const int off = (int)(d.x & 8191u), cnt = (int)((d.x >> 13) & 63u) + 1;
             double g0 = 0.0, g1 = 0.0;
