@@ -364,7 +364,7 @@ def run(args):
         shard_s.sh.close()
 
     route = (os.environ.get('FEP_P1_PATH', '') or 'node') if et == 'P1' else 'element'
-    patch_form = os.environ.get('FEP_GEN_PATH', 'coo' if et == 'Q2' else 'patch') != 'coo'      # the library's defaults
+    patch_form = os.environ.get('FEP_GEN_PATH', 'patch') != 'coo'      # the library's default
     if et != 'P1' or route == 'coo':
         # element route: strain + return map + K_e blocks in one kernel; patch form (default): closed CSR blocks written by the
         # same kernel, fixup_kernel for the node pairs on patch boundaries — the priced work is the pair

@@ -535,7 +535,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         // round 3, patch form of the element route: recomputed geometry wins for P2 as well (same session, 1 M elements:
         // 0.754 vs 0.783 ms on a fast box, 0.888 vs 0.936 on a slow one); the COO form keeps the streamed dphi arrays for P2
         const char* gpth = std::getenv("FEP_GEN_PATH");
-        const bool coo_form = gpth ? std::strcmp(gpth, "coo") == 0 : elem_type == FEP_Q2;
+        const bool coo_form = gpth && std::strcmp(gpth, "coo") == 0;
         c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : (elem_type == FEP_Q1 || elem_type == FEP_Q2 || (elem_type == FEP_P2 && !coo_form));
     }
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
@@ -543,12 +543,11 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
     if (const char* lp = std::getenv("FEP_ELEM_LDS_PAD")) c->lds_pad = std::max(0, std::atoi(lp));
     int elem_eb = 1;
-    // element route: the patch form (no K_e round trip through HBM) or the COO form (FEP_GEN_PATH=patch | coo).  Default by
-    // what measured faster in one session at 0.25-4 M elements (profiles/r03_ablation.md): patch for P2 (-7 %, K,F-only -13 %,
-    // BASELINE configs[4] -8 %), Q1 (-10 %), P4 (-12 %) and P1; COO for Q2, whose patch form won at 250 k elements (-3 %) and
-    // lost at 500 k (+10 %) — its element kernel holds three workgroups per CU either way and pays most for phase 3
+    // element route: the patch form (no K_e round trip through HBM; default) or the COO form (FEP_GEN_PATH=patch | coo).
+    // Same session, 0.25-4 M elements (profiles/r03_ablation.md, r03_elem_bench.log): P2 -17 % (K,F-only -19 %, BASELINE
+    // configs[4] -14 %), Q2 -14 %, Q1 -13 %, P4 -21 % against the COO form
     const char* gen_path = std::getenv("FEP_GEN_PATH");
-    const bool want_patch = !c->p1_node && !c->gn && (gen_path ? std::strcmp(gen_path, "coo") != 0 : elem_type != FEP_Q2);
+    const bool want_patch = !c->p1_node && !c->gn && !(gen_path && std::strcmp(gen_path, "coo") == 0);
     if (const char* tp = std::getenv("FEP_PATCH_TPB")) c->patch_tpb = (want_patch && std::atoi(tp) == 512 && elem_type == FEP_P2) ? 512 : 256;
     switch (elem_type) {
         case FEP_P1: elem_eb = c->elem_geo ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB; break;
@@ -564,13 +563,11 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
             fep_host::PatchOptions popt;
             if (const char* po = std::getenv("FEP_PATCH_ORDER"))
                 popt.order = std::strcmp(po, "consecutive") == 0 ? 0 : std::strcmp(po, "hilbert") == 0 ? 1 : 2;
+            popt.runs = elem_type == FEP_Q1 ? 4 : 2;                     // Q1 (64 elements per patch): 4 runs of 16 measured 6 % faster than 2 of 32
             if (const char* pr = std::getenv("FEP_PATCH_RUNS")) popt.runs = std::max(1, std::atoi(pr));
-            {   // elements per full 128-byte line of a point array row: 16 / gcd(16, n_q)
-                int g = 16, b = n_q;
-                while (b) { const int t = g % b; g = b; b = t; }
-                popt.align = 16 / g;
-                if (const char* pa = std::getenv("FEP_PATCH_ALIGN")) popt.align = std::max(1, std::atoi(pa));
-            }
+            // runs starting on 128-byte boundaries of the point arrays (16 / gcd(16, n_q) elements) measured no faster and
+            // cost a third more partials (the aligned starts leave short leftovers): off unless asked for
+            if (const char* pa = std::getenv("FEP_PATCH_ALIGN")) popt.align = std::max(1, std::atoi(pa));
             CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
             if (r == FEP_OK && P.ok && std::getenv("FEP_VALIDATE_PLAN")) {
                 const int bad = fep_host::validate_patch_plan(P, S, n_p, n_e, n_n, elements_h);

@@ -780,7 +780,7 @@ inline uint32_t hilbert_d(uint32_t x, uint32_t y) {
 // pieces): the first run starts at the lowest unassigned element; every further one is the longest run of consecutive,
 // still unassigned ids among the elements that share a node with the run before (on a row-numbered mesh: the same cells
 // one row up), so that a patch is `runs` rows high instead of one — its perimeter, hence what it exchanges with its
-// neighbours, shrinks accordingly.  A patch that stays short is topped up from the lowest unassigned ids.
+// neighbours, shrinks accordingly.  A patch that stays short is topped up from its own unassigned neighbours.
 inline void patch_runs(const Symbolic& S, int n_p, int64_t n_e, const int32_t* elem, int eb, int runs, int align,
                        std::vector<int32_t>& pel, std::vector<int32_t>& patch_of) {
     align = std::max(1, align);
@@ -798,7 +798,17 @@ inline void patch_runs(const Symbolic& S, int n_p, int64_t n_e, const int32_t* e
         for (int r = 0; r < runs && (int)cur.size() < eb; ++r) {
             const int budget = (eb - (int)cur.size() + (runs - r) - 1) / (runs - r);     // an even share of what is left
             const size_t run0 = cur.size();
-            for (int64_t e = start; e < n_e && patch_of[e] < 0 && (int)(cur.size() - run0) < budget; ++e) { cur.push_back((int32_t)e); patch_of[e] = p; }
+            // a run is consecutive ids that are also neighbours in the mesh: it ends where element e shares no node with e - 1
+            // (the end of a row of a row-numbered mesh — running on into the next row shears every patch of the band behind it)
+            for (int64_t e = start; e < n_e && patch_of[e] < 0 && (int)(cur.size() - run0) < budget; ++e) {
+                if (e > start) {
+                    bool touch = false;
+                    for (int a = 0; a < n_p && !touch; ++a)
+                        for (int b = 0; b < n_p && !touch; ++b) touch = elem[(int64_t)a * n_e + e] == elem[(int64_t)b * n_e + e - 1];
+                    if (!touch) break;
+                }
+                cur.push_back((int32_t)e); patch_of[e] = p;
+            }
             if (r + 1 == runs || (int)cur.size() >= eb) break;
             nbrs.clear();
             for (size_t i = run0; i < cur.size(); ++i)
@@ -828,8 +838,20 @@ inline void patch_runs(const Symbolic& S, int n_p, int64_t n_e, const int32_t* e
                 else if (lo + align < (int64_t)nbrs[best] + (int64_t)best_len) start = lo + align;
             }
         }
-        for (int64_t e = cursor; e < n_e && (int)cur.size() < eb; ++e)                   // top up
-            if (patch_of[e] < 0) { cur.push_back((int32_t)e); patch_of[e] = p; }
+        if ((int)cur.size() < eb) {                     // top up, with unassigned NEIGHBOURS of the patch only (lowest ids first): a patch
+            nbrs.clear();                               // that stays short costs a partly idle workgroup, one that collects far-away
+            for (size_t i = 0; i < cur.size(); ++i)     // elements costs every patch around them
+                for (int a = 0; a < n_p; ++a) {
+                    const int32_t nd = elem[(int64_t)a * n_e + cur[i]];
+                    for (int32_t t = S.iptr[nd]; t < S.iptr[nd + 1]; ++t) {
+                        const int32_t e2 = (int32_t)((int64_t)S.ilist[t] % n_e);
+                        if (patch_of[e2] < 0) nbrs.push_back(e2);
+                    }
+                }
+            std::sort(nbrs.begin(), nbrs.end());
+            nbrs.erase(std::unique(nbrs.begin(), nbrs.end()), nbrs.end());
+            for (size_t i = 0; i < nbrs.size() && (int)cur.size() < eb; ++i) { cur.push_back(nbrs[i]); patch_of[nbrs[i]] = p; }
+        }
         std::sort(cur.begin(), cur.end());
         pel.insert(pel.end(), cur.begin(), cur.end());
         pel.resize((size_t)(p + 1) * eb, -1);
