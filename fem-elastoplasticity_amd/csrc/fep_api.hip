@@ -548,27 +548,47 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     // configs[4] -14 %), Q2 -14 %, Q1 -13 %, P4 -21 % against the COO form
     const char* gen_path = std::getenv("FEP_GEN_PATH");
     const bool want_patch = !c->p1_node && !c->gn && !(gen_path && std::strcmp(gen_path, "coo") == 0);
-    if (const char* tp = std::getenv("FEP_PATCH_TPB")) c->patch_tpb = (want_patch && std::atoi(tp) == 512 && elem_type == FEP_P2) ? 512 : 256;
-    switch (elem_type) {
-        case FEP_P1: elem_eb = c->elem_geo ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB; break;
-        case FEP_P2: elem_eb = c->patch_tpb == 512 ? (c->elem_geo ? ElemCfg<6, 7, true, 512>::EB : ElemCfg<6, 7, false, 512>::EB)
-                                                  : (c->elem_geo ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB); break;
-        case FEP_Q1: elem_eb = c->elem_geo ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB; break;
-        case FEP_Q2: elem_eb = c->elem_geo ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB; break;
-        case FEP_P4: elem_eb = c->elem_geo ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB; break;
-    }
+    // P2 patches: 56 elements on 512 threads (two workgroups of eight waves per CU instead of four of four: the same waves,
+    // 2.0 instead of 3.2 partials per element with four runs, fix-up kernel -35 %, element kernel +3-12 %): three boxes, same
+    // session each: 1 M elements 0.653 / 0.681 / 0.724 against 0.700 / 0.713 / 0.716 ms, BASELINE configs[4] 2.61 / 2.89 / 2.89
+    // against 2.86 / 3.09 / 3.00, K,F-only 0.613 against 0.653; FEP_PATCH_TPB=256|512 forces one
+    const char* tpb_env = std::getenv("FEP_PATCH_TPB");
+    // (Q2 with 40 elements on 512 threads, 3.5 instead of 5.8 partials per element: 0.76-0.80 against 0.62 ms, not kept)
+    const bool p2_patch = want_patch && elem_type == FEP_P2;
+    c->patch_tpb = !p2_patch ? 256 : tpb_env ? (std::atoi(tpb_env) == 512 ? 512 : 256) : 512;
+    const auto elements_per_workgroup = [&]() {
+        const bool g = c->elem_geo;
+        switch (elem_type) {
+            case FEP_P1: return g ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB;
+            case FEP_P2: return c->patch_tpb == 512 ? (g ? ElemCfg<6, 7, true, 512>::EB : ElemCfg<6, 7, false, 512>::EB)
+                                                    : (g ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB);
+            case FEP_Q1: return g ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB;
+            case FEP_Q2: return g ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB;
+            case FEP_P4: return g ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB;
+        }
+        return 1;
+    };
+    elem_eb = elements_per_workgroup();
     if (!c->p1_node && !c->gn && r == FEP_OK) {
         if (want_patch) {
             fep_host::PatchPlan P;
             fep_host::PatchOptions popt;
             if (const char* po = std::getenv("FEP_PATCH_ORDER"))
                 popt.order = std::strcmp(po, "consecutive") == 0 ? 0 : std::strcmp(po, "hilbert") == 0 ? 1 : 2;
-            popt.runs = elem_type == FEP_Q1 ? 4 : 2;                     // Q1 (64 elements per patch): 4 runs of 16 measured 6 % faster than 2 of 32
+            // Q1 (64 elements per patch): 4 runs of 16 measured 6 % faster than 2 of 32; P2 with 56 elements: 4 runs of 14
+            // (1.96 partials per element) 1-3 % faster than 2 of 28 (2.86); with 28 elements 2 runs of 14 (4 of 7: +7 %)
+            popt.runs = (elem_type == FEP_Q1 || c->patch_tpb == 512) ? 4 : 2;
             if (const char* pr = std::getenv("FEP_PATCH_RUNS")) popt.runs = std::max(1, std::atoi(pr));
             // runs starting on 128-byte boundaries of the point arrays (16 / gcd(16, n_q) elements) measured no faster and
             // cost a third more partials (the aligned starts leave short leftovers): off unless asked for
             if (const char* pa = std::getenv("FEP_PATCH_ALIGN")) popt.align = std::max(1, std::atoi(pa));
             CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
+            if (r == FEP_OK && !P.ok && c->patch_tpb == 512 && !tpb_env) {     // the big patches cannot be built: the small ones
+                c->patch_tpb = 256;                                            // (a forced size is never changed silently)
+                elem_eb = elements_per_workgroup();
+                if (!std::getenv("FEP_PATCH_RUNS")) popt.runs = 2;
+                CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
+            }
             if (r == FEP_OK && P.ok && std::getenv("FEP_VALIDATE_PLAN")) {
                 const int bad = fep_host::validate_patch_plan(P, S, n_p, n_e, n_n, elements_h);
                 if (bad) { std::fprintf(stderr, "[fep] patch plan fails check %d\n", bad); r = FEP_EINVAL; }
@@ -599,7 +619,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         }
         c->n_count_blocks = c->patch ? (int)c->n_patch : (int)grid_for(n_e, elem_eb);
     }
-    if (!c->patch && c->patch_tpb != 256) r = r == FEP_OK ? FEP_ESTATE : r;        // (a 512-thread plan that could not be built: no silent change of patch size)
+    if (!c->patch && c->patch_tpb != 256) r = r == FEP_OK ? FEP_ESTATE : r;        // (a forced 512-thread plan that could not be built)
     if (!c->patch) {
         CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
         CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
@@ -747,8 +767,6 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
 #define ELEM_LAUNCH_T(GEO, PATCH, TPB)                                                                                   \
     do {                                                                                                                 \
         if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO, TPB>::EB) return FEP_ESTATE;                        \
-        if (sizeof(double) * ElemCfg<NP, NQ, GEO, TPB>::kPts > 64 * 1024)                                                \
-            (void)0;                                                                                                     \
         hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB>),                                           \
                            dim3(PATCH ? (unsigned)c->n_patch : grid_for(c->n_e, ElemCfg<NP, NQ, GEO, TPB>::EB)),           \
                            dim3(TPB), (size_t)c->lds_pad, st, c->n_e,                                                   \
@@ -757,9 +775,8 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
                            PATCH ? nullptr : Kc, PATCH ? nullptr : fe, c->kc_aos ? 1 : 0, pa);                          \
     } while (0)
     if (c->patch && c->patch_tpb == 512) {
-        // (P2 only: the one element type the 512-thread patch has been measured on)
         if constexpr (NP == 6 && NQ == 7) { if (c->elem_geo) ELEM_LAUNCH_T(true, true, 512); else ELEM_LAUNCH_T(false, true, 512); }
-        else return FEP_ESTATE;
+        else return FEP_ESTATE;                          // (P2 is the one element type with a 512-thread form)
     }
     else if (c->patch) { if (c->elem_geo) ELEM_LAUNCH(true, true); else ELEM_LAUNCH(false, true); }
     else { if (c->elem_geo) ELEM_LAUNCH(true, false); else ELEM_LAUNCH(false, false); }

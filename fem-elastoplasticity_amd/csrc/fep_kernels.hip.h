@@ -16,6 +16,14 @@ namespace fep {
 
 constexpr int kBlock = 256;
 
+// -DFEP_P2_FMA=1: phase 2 of element_kernel with every product fused into its accumulator (57 instead of 84 vector
+// instructions per point and lane; K differs in the last bits).  Measured in one session against the default: P2 1 M elements
+// +2 % (0.700 against 0.686 ms), Q2 +2.5 %, P4 / Q1 equal, BASELINE configs[4] -2.5 %: the arithmetic of phase 2 is not what
+// the kernel waits for.  Off.
+#ifndef FEP_P2_FMA
+#define FEP_P2_FMA 0
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding global stores
 // (s_waitcnt vmcnt(0)): behind a phase that has just issued its output stores that wait is a full store round trip on
 // the workgroup's critical path.  Use where the phases exchange data through LDS alone.
@@ -298,8 +306,8 @@ template <int NP, int NQ, bool GEO = false, int TPB = kBlock> struct ElemCfg {
     // with the coordinate staging of GEO the big elements take fewer per workgroup, so that the LDS still admits
     // as many resident workgroups as without it (P2: 4 per CU, Q2: 3)
     // (the 15-node element: 16 instead of 17, so that two workgroups with their gather codes fit a CU's LDS)
-    // TPB = 512 (patch form, FEP_PATCH_TPB=512): twice the elements per workgroup — a patch four runs high with runs as long
-    // as before — at the same waves per CU (two workgroups of eight waves)
+    // TPB = 512 (patch form; P2's default): twice the elements per workgroup — a patch four runs high with runs as long as
+    // before — at the same waves per CU (two workgroups of eight waves)
     static constexpr int S = TPB / kBlock;
     static constexpr int EB = NP == 15 ? 16 * S : !GEO ? (NP == 6 && NQ == 7 && S == 2 ? 60 : EB0)
                                                        : (NP == 6 && NQ == 7) ? 28 * S : (NP == 8 && NQ == 9) ? 24 * S : EB0;
@@ -420,7 +428,11 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 #pragma unroll
             for (int a = 0; a < NP; ++a) {
                 const double2 u = cu[a][el];
-                ev[0] += g1[a] * u.x; ev[1] += g2[a] * u.y; ev[2] += g2[a] * u.x + g1[a] * u.y;   // DP:1043
+                // DP:1043.  Written out in fused multiply-adds: which of two products the compiler fuses is its choice, and
+                // it chose differently in the 256- and the 512-thread instantiation (point outputs differed in the last bit)
+                ev[0] = __builtin_fma(g1[a], u.x, ev[0]);
+                ev[1] = __builtin_fma(g2[a], u.y, ev[1]);
+                ev[2] += __builtin_fma(g1[a], u.y, g2[a] * u.x);
             }
             double p[4] = {0.0, 0.0, 0.0, 0.0};
             if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
@@ -460,11 +472,26 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             const double D00 = Ds[0][li], D01 = Ds[1][li], D02 = Ds[2][li];
             const double D11 = Ds[3][li], D12 = Ds[4][li], D22 = Ds[5][li];
             const double a1 = d1s[a][li], a2 = d2s[a][li];
-            f0 += a1 * Ss[0][li] + a2 * Ss[2][li];
-            f1 += a2 * Ss[1][li] + a1 * Ss[2][li];
             // rows of B_a^T D:  r0 = (a1,0,a2) D,  r1 = (0,a2,a1) D
             const double r00 = a1 * D00 + a2 * D02, r01 = a1 * D01 + a2 * D12, r02 = a1 * D02 + a2 * D22;
             const double r10 = a2 * D01 + a1 * D02, r11 = a2 * D11 + a1 * D12, r12 = a2 * D12 + a1 * D22;
+#if FEP_P2_FMA
+            // every product goes into its accumulator with one fused multiply-add (two per entry and point instead of
+            // multiply, multiply-add, add)
+            f0 = __builtin_fma(a1, Ss[0][li], __builtin_fma(a2, Ss[2][li], f0));
+            f1 = __builtin_fma(a2, Ss[1][li], __builtin_fma(a1, Ss[2][li], f1));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int b = a + j >= NP ? a + j - NP : a + j;
+                const double b1 = d1s[b][li], b2 = d2s[b][li];
+                kk[j][0] = __builtin_fma(r00, b1, __builtin_fma(r02, b2, kk[j][0]));
+                kk[j][1] = __builtin_fma(r01, b2, __builtin_fma(r02, b1, kk[j][1]));
+                kk[j][2] = __builtin_fma(r10, b1, __builtin_fma(r12, b2, kk[j][2]));
+                kk[j][3] = __builtin_fma(r11, b2, __builtin_fma(r12, b1, kk[j][3]));
+            }
+#else
+            f0 += a1 * Ss[0][li] + a2 * Ss[2][li];
+            f1 += a2 * Ss[1][li] + a1 * Ss[2][li];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int b = a + j >= NP ? a + j - NP : a + j;
@@ -474,6 +501,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                 kk[j][2] += r10 * b1 + r12 * b2;
                 kk[j][3] += r11 * b2 + r12 * b1;
             }
+#endif
         }
     }
     if (!PATCH) {

@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
         const int64_t side = (int64_t)std::ceil(std::sqrt((double)n_n));
         for (int64_t n = 0; n < n_n; ++n) { xy[n] = (double)(n % side); xy[n_n + n] = (double)(n / side); }
         if (have_coords) xy = coords;
-        const int ebs_np[][4] = {{3, 64, 7, 1}, {6, 32, 28, 5}, {4, 64, 9, 2}, {8, 28, 24, 3}, {15, 16, 4, 1}};
+        const int ebs_np[][4] = {{3, 64, 7, 1}, {6, 56, 28, 5}, {4, 64, 9, 2}, {8, 28, 24, 3}, {15, 16, 4, 1}};
         for (const auto& row : ebs_np) {
             if (row[0] != n_p) continue;
             for (int k = 1; k < 4; ++k)

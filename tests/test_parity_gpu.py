@@ -356,8 +356,13 @@ def test_patch_route_against_the_coo_route(fep, monkeypatch, name):
     monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
     monkeypatch.setenv('FEP_P1_PATH', 'coo')
     res = {}
-    for route in ('coo', 'patch'):
-        monkeypatch.setenv('FEP_GEN_PATH', route)
+    # P2 has patches of two sizes (28 elements on 256 threads, 56 on 512: the default)
+    routes = ('coo', 'patch') + (('patch256', 'patch512') if t == 'P2' else ())
+    for route in routes:
+        monkeypatch.setenv('FEP_GEN_PATH', route[:5] if route.startswith('patch') else route)
+        monkeypatch.delenv('FEP_PATCH_TPB', raising=False)
+        if route[5:]:
+            monkeypatch.setenv('FEP_PATCH_TPB', route[5:])
         ctx = fep.MeshContext(elem, coord)
         ctx.set_materials(*dp_materials(n))
         F_poison = ctx.step(1e3 * U, None, want=('K', 'F'))                   # other values in the scratch buffers
@@ -374,15 +379,17 @@ def test_patch_route_against_the_coo_route(fep, monkeypatch, name):
         assert np.array_equal(F3, r['F']) and np.array_equal(K3.data, r['K'].data)
         res[route] = (r, ep)
         ctx.close()
-    a, b = res['coo'][0], res['patch'][0]
-    assert (a['n_smooth'] > 0 or n < 100) and (a['n_smooth'], a['n_apex']) == (b['n_smooth'], b['n_apex'])
-    for k in ('E', 's', 'ds', 'ind_p'):
-        assert np.array_equal(a[k], b[k]), k
-    assert np.array_equal(res['coo'][1], res['patch'][1])
-    assert relerr(b['K'].data, a['K'].data) <= 1e-13 and relerr(b['F'], a['F']) <= 1e-13
-    assert relerr_rows(b['K'], a['K']) <= 1e-12
-    if name == 'orphans_Q2':
-        assert b['F'][2 * 50] == 0 and b['F'][2 * 50 + 1] == 0 and b['F'][-1] == 0 and b['F'][-2] == 0
+    a = res['coo'][0]
+    for route in routes[1:]:
+        b = res[route][0]
+        assert (a['n_smooth'] > 0 or n < 100) and (a['n_smooth'], a['n_apex']) == (b['n_smooth'], b['n_apex'])
+        for k in ('E', 's', 'ds', 'ind_p'):
+            assert np.array_equal(a[k], b[k]), (route, k)
+        assert np.array_equal(res['coo'][1], res[route][1])
+        assert relerr(b['K'].data, a['K'].data) <= 1e-13 and relerr(b['F'], a['F']) <= 1e-13
+        assert relerr_rows(b['K'], a['K']) <= 1e-12
+        if name == 'orphans_Q2':
+            assert b['F'][2 * 50] == 0 and b['F'][2 * 50 + 1] == 0 and b['F'][-1] == 0 and b['F'][-2] == 0
 
 
 @pytest.mark.parametrize('t,N', [('P2', 24), ('Q1', 40), ('Q2', 20)])
