@@ -63,6 +63,8 @@ PROTOTYPES = {
     'fep_solver_pcg_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                      C.c_int, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)]),
     'fep_solver_amg_clear': (C.c_int, [C.c_void_p]),
+    'fep_solver_amg_enable_refresh': (C.c_int, [C.c_void_p]),
+    'fep_solver_amg_refresh_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_solver_amg_push_level': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 12 + [C.c_double, C.c_int]),
     'fep_solver_amg_pcg_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                          C.c_int, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)]),

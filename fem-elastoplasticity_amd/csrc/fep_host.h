@@ -1357,4 +1357,101 @@ inline int aggregate(int64_t n, const int32_t* indptr, const int32_t* indices, i
     return FEP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Sparse products on FIXED patterns (multigrid: coarse operators re-projected from every tangent, A' = R A P with the
+// transfers of the hierarchy).  The symbolic work is done once on the host: the pattern of X*Y, and for a given output
+// pattern the TERMS of every output entry, C[c] = sum_t X[xa[t]] * Y[ya[t]], t in [tptr[c], tptr[c+1]) in ascending order
+// of the X entry — the numeric phase on the device is one gather-multiply-add loop per entry, in a fixed order.
+// ---------------------------------------------------------------------------------------
+// pattern of X*Y (rows of X, columns of Y), column ids ascending per row
+inline int product_pattern(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* Xp, const int32_t* Xi, const int32_t* Yp,
+                           const int32_t* Yi, std::vector<int32_t>& Cp, std::vector<int32_t>& Ci) {
+    if (n_rows < 0 || n_mid < 0 || n_cols < 0 || !Xp || !Yp) return FEP_EINVAL;
+    std::vector<int32_t> cnt((size_t)n_rows, 0);
+    std::atomic<int> bad{0};
+    auto row_cols = [&](int64_t i, std::vector<int32_t>& buf) {
+        buf.clear();
+        for (int32_t x = Xp[i]; x < Xp[i + 1]; ++x) {
+            const int32_t j = Xi[x];
+            if (j < 0 || j >= n_mid) { bad = 1; return; }
+            for (int32_t y = Yp[j]; y < Yp[j + 1]; ++y) {
+                if (Yi[y] < 0 || Yi[y] >= n_cols) { bad = 1; return; }
+                buf.push_back(Yi[y]);
+            }
+        }
+        std::sort(buf.begin(), buf.end());
+        buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+    };
+    parallel_chunks(n_rows, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> buf;
+        for (int64_t i = lo; i < hi; ++i) { row_cols(i, buf); cnt[(size_t)i] = (int32_t)buf.size(); }
+    });
+    if (bad) return FEP_ERANGE;
+    Cp.assign((size_t)n_rows + 1, 0);
+    int64_t tot = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        tot += cnt[(size_t)i];
+        if (tot >= INT32_MAX) return FEP_ERANGE;
+        Cp[(size_t)i + 1] = (int32_t)tot;
+    }
+    Ci.resize((size_t)tot);
+    parallel_chunks(n_rows, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> buf;
+        for (int64_t i = lo; i < hi; ++i) { row_cols(i, buf); std::copy(buf.begin(), buf.end(), Ci.begin() + Cp[(size_t)i]); }
+    });
+    return FEP_OK;
+}
+
+struct ProductPlan {
+    std::vector<int32_t> tptr, xa, ya;       // terms of output entry c: xa / ya [tptr[c] .. tptr[c+1])
+};
+
+// terms of C = X*Y on the pattern (Cp, Ci) (column ids ascending per row; `dense_cols` > 0: C is dense with that many columns
+// and Cp / Ci are not read).  FEP_EINVAL when a structural term of the product has no entry in the pattern.
+inline int product_plan(int64_t n_rows, int64_t n_mid, const int32_t* Xp, const int32_t* Xi, const int32_t* Yp, const int32_t* Yi,
+                        const int32_t* Cp, const int32_t* Ci, int64_t dense_cols, ProductPlan& P) {
+    if (n_rows < 0 || !Xp || !Yp || (!dense_cols && (!Cp || !Ci))) return FEP_EINVAL;
+    const int64_t n_out = dense_cols ? n_rows * dense_cols : Cp[n_rows];
+    if (n_out >= INT32_MAX) return FEP_ERANGE;
+    std::vector<int32_t> cnt((size_t)n_out + 1, 0);
+    std::atomic<int> bad{0};
+    int64_t n_cols = dense_cols;
+    if (!dense_cols)
+        for (int64_t c = 0; c < n_out; ++c) n_cols = std::max<int64_t>(n_cols, (int64_t)Ci[c] + 1);
+    // position of column J in row i of C through a per-thread map column -> entry (entries of other rows fail the range test)
+    auto walk = [&](int64_t lo, int64_t hi, bool fill) {
+        std::vector<int32_t> pos(dense_cols ? 0 : (size_t)n_cols, -1);
+        for (int64_t i = lo; i < hi && !bad; ++i) {
+            if (!dense_cols)
+                for (int32_t c = Cp[i]; c < Cp[i + 1]; ++c) pos[(size_t)Ci[c]] = c;
+            for (int32_t x = Xp[i]; x < Xp[i + 1]; ++x) {
+                const int32_t j = Xi[x];
+                if (j < 0 || j >= n_mid) { bad = 2; return; }
+                for (int32_t y = Yp[j]; y < Yp[j + 1]; ++y) {
+                    const int32_t J = Yi[y];
+                    int64_t c = -1;
+                    if (J >= 0 && J < n_cols) c = dense_cols ? i * dense_cols + J : (int64_t)pos[(size_t)J];
+                    if (c < 0 || (!dense_cols && (c < Cp[i] || c >= Cp[i + 1]))) { bad = 1; return; }
+                    if (!fill) { ++cnt[(size_t)c + 1]; continue; }
+                    const int32_t t = P.tptr[(size_t)c] + cnt[(size_t)c]++;
+                    P.xa[(size_t)t] = x; P.ya[(size_t)t] = y;
+                }
+            }
+        }
+    };
+    parallel_chunks(n_rows, [&](int64_t lo, int64_t hi, int) { walk(lo, hi, false); });      // rows own their output entries
+    if (bad) return bad == 1 ? FEP_EINVAL : FEP_ERANGE;
+    P.tptr.assign((size_t)n_out + 1, 0);
+    int64_t tot = 0;
+    for (int64_t c = 0; c < n_out; ++c) {
+        tot += cnt[(size_t)c + 1];
+        if (tot >= INT32_MAX) return FEP_ERANGE;
+        P.tptr[(size_t)c + 1] = (int32_t)tot;
+    }
+    P.xa.resize((size_t)tot); P.ya.resize((size_t)tot);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    parallel_chunks(n_rows, [&](int64_t lo, int64_t hi, int) { walk(lo, hi, true); });
+    return bad ? FEP_EINVAL : FEP_OK;
+}
+
 }  // namespace fep_host

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <cstdlib>
@@ -221,10 +222,12 @@ pcg_scalar_kernel(Scal* sc, const double* part_g, const double* part_r, int n_ve
 // out = x + omega M^-1 Q (b - K x)   (x != out).
 // SMOOTH = 2: the second step of a degree-2 Chebyshev smoother,
 //   out = ca x + cprev xprev + omega M^-1 Q (b - K x)      (xprev == nullptr: that term is absent).
-template <int SMOOTH>
+// KV = float2: the V-cycle's passes read a single-precision copy of K (half the bytes of the pass; the preconditioner need not
+// see more than seven digits of the matrix, the outer iteration's own product stays in double precision).
+template <int SMOOTH, typename KV>
 __global__ void __launch_bounds__(TPB)
 block_residual_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32_t* __restrict__ ncol,
-                      const uint8_t* __restrict__ free_dof, const double2* __restrict__ K2,
+                      const uint8_t* __restrict__ free_dof, const KV* __restrict__ K2,
                       const double2* __restrict__ x, const double* __restrict__ b, const double* __restrict__ minv,
                       double omega, double* __restrict__ out,
                       double ca = 1.0, double cprev = 0.0, const double2* __restrict__ xprev = nullptr) {
@@ -238,13 +241,13 @@ block_residual_kernel(int64_t n_n, const int32_t* __restrict__ nptr, const int32
         acc0[ps] = 0.0; acc1[ps] = 0.0;
         if (n < n_n) {
             const int b0 = nptr[n], deg = nptr[n + 1] - b0;
-            const double2* row0 = K2 + 2 * (int64_t)b0;
-            const double2* row1 = row0 + deg;
+            const KV* row0 = K2 + 2 * (int64_t)b0;
+            const KV* row1 = row0 + deg;
             for (int t = sub; t < deg; t += 8) {
-                const double2 k0 = row0[t], k1 = row1[t];
+                const KV k0 = row0[t], k1 = row1[t];
                 const double2 xv = x[ncol[b0 + t]];
-                acc0[ps] += k0.x * xv.x + k0.y * xv.y;
-                acc1[ps] += k1.x * xv.x + k1.y * xv.y;
+                acc0[ps] += (double)k0.x * xv.x + (double)k0.y * xv.y;
+                acc1[ps] += (double)k1.x * xv.x + (double)k1.y * xv.y;
             }
         }
     }
@@ -292,24 +295,34 @@ block_scale_kernel(int64_t n_n, const uint8_t* __restrict__ free_dof, const doub
     x[n] = make_double2(omega * (m0 * r.x + m1 * r.y), omega * (m1 * r.x + m2 * r.y));
 }
 
+// single-precision copy of K for the V-cycle (one pass per solve)
+__global__ void __launch_bounds__(TPB)
+to_float_kernel(int64_t n4, const double4* __restrict__ in, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n4) return;
+    const double4 v = in[i];
+    out[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+
 // Coarse levels and transfers: scalar CSR, 8 lanes per row:  y = c0 * z + c1 * A x   (z == nullptr: y = c1 * A x;
 // y may alias z, never x)
 // Z2: y = c0 * z + c2 * z2 + c1 * A x  (y may alias z or z2)
-template <bool Z2>
+// LPR lanes per row: 8 for operator / restriction rows (30-70 entries), 2 for prolongation rows (~7 entries: with 8 lanes a
+// wave carried 450 bytes of matrix)
+template <bool Z2, int LPR>
 __global__ void __launch_bounds__(TPB)
 csr_kernel(int64_t n_rows, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
            const double* __restrict__ vals, const double* __restrict__ x, const double* z, double c0, double c1,
            double* y, const double* z2 = nullptr, double c2 = 0.0) {
-    const int sub = threadIdx.x & 7;
-    const int64_t row = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & (LPR - 1);
+    const int64_t row = ((int64_t)blockIdx.x * TPB + threadIdx.x) / LPR;
     double a = 0.0;
     if (row < n_rows) {
         const int32_t e = indptr[row + 1];
-        for (int32_t t = indptr[row] + sub; t < e; t += 8) a += vals[t] * x[indices[t]];
+        for (int32_t t = indptr[row] + sub; t < e; t += LPR) a += vals[t] * x[indices[t]];
     }
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 4, 64);
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) a += __shfl_xor(a, o, 64);
     if (row < n_rows && sub == 0) {
         if (Z2) y[row] = c0 * z[row] + c2 * z2[row] + c1 * a;
         else y[row] = (z ? c0 * z[row] : 0.0) + c1 * a;
@@ -410,6 +423,145 @@ mg_scalar_kernel(Scal* sc, int which, const double* part_a, int n_a, const doubl
     *sc = s;
 }
 
+
+// ---- coarse operators re-projected from the current tangent (fep_solver_amg_enable_refresh) ----
+// One entry of a sparse product on fixed patterns per thread: out[c] = sum_t coef[t] * V[idx[t]] over the entry's terms
+// (fep_host.h: product_plan), in the plan's order.  One factor of either product is a transfer matrix, fixed since the
+// set-up: its value rides in the term (one 16-byte load per term and one gather instead of two index loads and two gathers:
+// 5.4 -> ... ms per refresh at 1 M DOFs).
+struct Term { double coef; int32_t idx; int32_t pad; };
+// set-up: the terms from the plan's index pairs; the constant factor's values are on the device already (`first`: it is the
+// first factor — R in R * T — else the second — P in A * P)
+__global__ void __launch_bounds__(TPB)
+compose_terms_kernel(int64_t n, const int32_t* __restrict__ xa, const int32_t* __restrict__ ya, const double* __restrict__ cv,
+                     int first, Term* __restrict__ terms) {
+    const int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int32_t x = xa[t], y = ya[t];
+    terms[t] = first ? Term{cv[x], y, 0} : Term{cv[y], x, 0};
+}
+__global__ void __launch_bounds__(TPB)
+product_kernel(int64_t n_out, const int32_t* __restrict__ tptr, const Term* __restrict__ terms, const double* __restrict__ V,
+               double* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (c >= n_out) return;
+    double a = 0.0;
+    for (int32_t t = tptr[c], e = tptr[c + 1]; t < e; ++t) {
+        const int4 w = *reinterpret_cast<const int4*>(terms + t);
+        a += __hiloint2double(w.y, w.x) * V[w.z];
+    }
+    out[c] = a;
+}
+
+// D = inverse of the 3x3 diagonal blocks of a coarse operator, as solver.py builds it (_block_diag_inverse: an empty
+// row / column — a rotation nobody interpolates from — gets a unit diagonal; 1e-13 of the mean diagonal is added)
+__global__ void __launch_bounds__(TPB)
+block3_inverse_kernel(int64_t n_nodes, const int32_t* __restrict__ d9, const double* __restrict__ A, double* __restrict__ D) {
+    const int64_t n = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (n >= n_nodes) return;
+    double m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const int32_t q = d9[9 * n + i]; m[i] = q >= 0 ? A[q] : 0.0; }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) if (m[4 * b] == 0.0) m[4 * b] = 1.0;
+    const double eps = 1e-13 * fabs(m[0] + m[4] + m[8]) / 3.0;
+    m[0] += eps; m[4] += eps; m[8] += eps;
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double r = 1.0 / det;
+    double* o = D + 9 * n;
+    o[0] = c00 * r; o[1] = (m[2] * m[7] - m[1] * m[8]) * r; o[2] = (m[1] * m[5] - m[2] * m[4]) * r;
+    o[3] = c01 * r; o[4] = (m[0] * m[8] - m[2] * m[6]) * r; o[5] = (m[2] * m[3] - m[0] * m[5]) * r;
+    o[6] = c02 * r; o[7] = (m[1] * m[6] - m[0] * m[7]) * r; o[8] = (m[0] * m[4] - m[1] * m[3]) * r;
+}
+
+// Coarse levels under the refresh: three DOFs per node and the three rows of a node stored back to back on the SAME block
+// columns (the refresh pads its product pattern to whole 3x3 blocks), so one group of 8 lanes forms all three sums of a
+// node from one pass over its block columns (ids and x fetched once) and applies the node's 3x3 block-Jacobi inverse on the
+// spot — the smoothing step that took an operator pass and a D pass is one kernel:
+//   MODE 0: out = b - A x      MODE 1: out = x + om D (b - A x)      MODE 2: out = ca x + cp xp + om D (b - A x)
+// out never aliases x (neighbours read it); it may alias xp.
+template <int MODE>
+__global__ void __launch_bounds__(TPB)
+node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __restrict__ nbc, const double* __restrict__ A,
+             const double* __restrict__ D, const double* __restrict__ x, const double* __restrict__ b, double om, double ca,
+             double cp, const double* xp, double* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 7, grp = lane >> 3;
+    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + grp;
+    double acc[SPMV_PASSES][3];
+#pragma unroll
+    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+        const int64_t n = node0 + ps * NODES_PER_WAVE;
+        acc[ps][0] = acc[ps][1] = acc[ps][2] = 0.0;
+        if (n < n_nodes) {
+            const int b0 = nbp[n], deg = nbp[n + 1] - b0;
+            const double* r0 = A + 9 * (int64_t)b0;
+            const double* r1 = r0 + 3 * deg;
+            const double* r2 = r1 + 3 * deg;
+            for (int t = sub; t < deg; t += 8) {
+                const double* xv = x + 3 * (int64_t)nbc[b0 + t];
+                const double x0 = xv[0], x1 = xv[1], x2 = xv[2];
+                acc[ps][0] += r0[3 * t] * x0 + r0[3 * t + 1] * x1 + r0[3 * t + 2] * x2;
+                acc[ps][1] += r1[3 * t] * x0 + r1[3 * t + 1] * x1 + r1[3 * t + 2] * x2;
+                acc[ps][2] += r2[3 * t] * x0 + r2[3 * t + 1] * x1 + r2[3 * t + 2] * x2;
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+        double a0 = acc[ps][0], a1 = acc[ps][1], a2 = acc[ps][2];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        const int64_t n = node0 + ps * NODES_PER_WAVE;
+        if (sub != 0 || n >= n_nodes) continue;
+        const double q0 = b[3 * n] - a0, q1 = b[3 * n + 1] - a1, q2 = b[3 * n + 2] - a2;
+        if (MODE == 0) { out[3 * n] = q0; out[3 * n + 1] = q1; out[3 * n + 2] = q2; continue; }
+        const double* d = D + 9 * n;
+        const double d0 = d[0] * q0 + d[1] * q1 + d[2] * q2, d1 = d[3] * q0 + d[4] * q1 + d[5] * q2, d2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
+        double o0 = x[3 * n], o1 = x[3 * n + 1], o2 = x[3 * n + 2];
+        if (MODE == 2) {
+            o0 *= ca; o1 *= ca; o2 *= ca;
+            if (xp) { o0 += cp * xp[3 * n]; o1 += cp * xp[3 * n + 1]; o2 += cp * xp[3 * n + 2]; }
+        }
+        out[3 * n] = o0 + om * d0; out[3 * n + 1] = o1 + om * d1; out[3 * n + 2] = o2 + om * d2;
+    }
+}
+
+// Coarsest operator (n <= kDenseMax, symmetric positive definite after the shift solver.py applies: 1e-10 of its largest
+// entry on the diagonal): inverted in place by one workgroup, Gauss-Jordan without pivoting, a fixed order.
+constexpr int kDenseMax = 256;             // (one workgroup: 1 ms at 128 DOFs, 7 ms at 256, 0.3 s at 900)
+__global__ void __launch_bounds__(1024)
+dense_inverse_kernel(int n, double* __restrict__ A) {
+    __shared__ double col[kDenseMax], row[kDenseMax];
+    __shared__ double sh[16];
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n * n; i += 1024) mx = fmax(mx, fabs(A[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = 0.0;
+    for (int i = 0; i < 16; ++i) mx = fmax(mx, sh[i]);
+    for (int i = threadIdx.x; i < n; i += 1024) A[(size_t)i * n + i] += 1e-10 * mx;
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        const double d = 1.0 / A[(size_t)p * n + p];
+        __syncthreads();                                           // (everybody has read the pivot)
+        for (int i = threadIdx.x; i < n; i += 1024) { col[i] = A[(size_t)i * n + p]; row[i] = A[(size_t)p * n + i] * d; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * n; e += 1024) {
+            const int i = e / n, j = e - i * n;
+            double v;
+            if (i == p) v = j == p ? d : row[j];
+            else if (j == p) v = -col[i] * d;
+            else v = A[e] - col[i] * row[j];
+            A[e] = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 struct fep_solver {
@@ -423,15 +575,30 @@ struct fep_solver {
     int n_vec_blocks = 0, n_mv_blocks = 0;
     // multigrid preconditioner: level k (k = 0 is the mesh) -> level k+1
     struct Csr { int64_t n_rows = 0, nnz = 0; int32_t *indptr = nullptr, *indices = nullptr; double* vals = nullptr; };
+    struct Plan { int64_t n_out = 0; int32_t* tptr = nullptr; void* terms = nullptr; };      // terms: (coefficient, value index) x 16 bytes
     struct Level {
         int64_t n_fine = 0, n_coarse = 0;
         Csr P, R, A, D;                       // A, D: operator of level k+1 (A = its inverse when last) and its block-Jacobi inverse
         double omega = 0.0;                   // damping of the smoother on level k
         bool last = false;
         double *x = nullptr, *b = nullptr, *r = nullptr, *t = nullptr;      // vectors of level k+1 (t: Chebyshev smoother)
+        std::vector<int32_t> hPp, hPi, hRp, hRi;                            // host patterns of the transfers (refresh plans)
+        // refresh: T = A_k P (values only), A_{k+1} = R T, positions of the 3x3 diagonal blocks in A_{k+1}
+        Plan ap, rt;
+        double* T = nullptr;
+        int32_t* d9 = nullptr;
+        int32_t *nbp = nullptr, *nbc = nullptr;                             // node blocks of the padded A (node3_kernel)
+        double* xcur = nullptr;                                             // which of x / t / r holds the level's iterate
     };
+    std::vector<int32_t> ip0, ix0;            // scalar pattern of K on the host (refresh plans)
+    bool refresh = false;                     // every multigrid solve re-projects the coarse operators from its tangent
     std::vector<Level> levels;
     double *t0 = nullptr, *q = nullptr;       // level-0 residual of the V-cycle, q = K p
+    // single-precision copy of the solve's K for the V-cycle's level-0 passes: FEP_AMG_FP32=1.  Measured at 1 M DOFs, BASELINE
+    // configs[3] end to end: 10.76 s with it, 10.86 s without, the same iteration counts — the passes wait for the gathered
+    // x, not for K's bytes.  Off.
+    float* k32 = nullptr;
+    bool fp32 = false;
     // smoother of the V-cycle: degree-2 Chebyshev (default) or two damped block-Jacobi sweeps (FEP_AMG_SMOOTHER=jacobi)
     bool cheb = true;
     double cheb_alpha = 20.0, cheb_safety = 1.2;          // K_elast at 1 M DOFs: alpha 5 / 10 / 20 / 30 -> 77 / 70 / 67 / 66 iterations (Jacobi: 90)
@@ -443,12 +610,20 @@ static void free_csr(fep_solver::Csr& m) {
     if (m.vals) (void)hipFree(m.vals);
     m = fep_solver::Csr();
 }
+static void free_plan(fep_solver::Plan& p) {
+    if (p.tptr) (void)hipFree(p.tptr);
+    if (p.terms) (void)hipFree(p.terms);
+    p = fep_solver::Plan();
+}
 static void free_levels(fep_solver* s) {
     for (auto& l : s->levels) {
         free_csr(l.P); free_csr(l.R); free_csr(l.A); free_csr(l.D);
-        for (double* v : {l.x, l.b, l.r, l.t}) if (v) (void)hipFree(v);
+        for (double* v : {l.x, l.b, l.r, l.t, l.T}) if (v) (void)hipFree(v);
+        free_plan(l.ap); free_plan(l.rt);
+        for (int32_t* v : {l.d9, l.nbp, l.nbc}) if (v) (void)hipFree(v);
     }
     s->levels.clear();
+    s->refresh = false;
 }
 
 extern "C" int fep_solver_destroy(fep_solver* s) {
@@ -460,6 +635,7 @@ extern "C" int fep_solver_destroy(fep_solver* s) {
             if (q) (void)hipFree(q);
         if (s->t0) (void)hipFree(s->t0);
         if (s->q) (void)hipFree(s->q);
+        if (s->k32) (void)hipFree(s->k32);
         free_levels(s);
     }
     delete s;
@@ -513,8 +689,11 @@ static int solver_create_impl(fep_solver** out, int device_id, int64_t n_n, cons
     if (!s) return FEP_ENOMEM;
     if (const char* sm = std::getenv("FEP_AMG_SMOOTHER")) s->cheb = std::strcmp(sm, "jacobi") != 0;
     if (const char* al = std::getenv("FEP_AMG_CHEB_ALPHA")) { const double v = std::atof(al); if (v > 1.0) s->cheb_alpha = v; }
+    if (const char* f32 = std::getenv("FEP_AMG_FP32")) s->fp32 = std::strcmp(f32, "0") != 0;
     if (const char* sf = std::getenv("FEP_AMG_CHEB_SAFETY")) { const double v = std::atof(sf); if (v >= 1.0) s->cheb_safety = v; }
     s->device = device_id; s->n_n = n_n; s->n_dof = n_dof; s->n_blk = n_blk;
+    s->ip0.assign(indptr_h, indptr_h + n_dof + 1);
+    s->ix0.assign(indices_h, indices_h + indptr_h[n_dof]);
     for (int64_t i = 0; i < n_dof; ++i) s->n_free += free_dof_h[i] != 0;
     s->n_vec_blocks = (int)((n_n + TPB - 1) / TPB);
     s->n_mv_blocks = (int)((n_n + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK);
@@ -635,12 +814,35 @@ static int upload_csr(fep_solver::Csr& m, int64_t n_rows, int64_t n_cols, const 
     return FEP_OK;
 }
 
+static int push_level_impl(fep_solver* s, int64_t n_fine, int64_t n_coarse,
+                           const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
+                           const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,
+                           const int32_t* a_indptr, const int32_t* a_indices, const double* a_vals,
+                           const int32_t* d_indptr, const int32_t* d_indices, const double* d_vals,
+                           double omega_fine, int last);
+
 extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t n_coarse,
                                          const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
                                          const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,
                                          const int32_t* a_indptr, const int32_t* a_indices, const double* a_vals,
                                          const int32_t* d_indptr, const int32_t* d_indices, const double* d_vals,
                                          double omega_fine, int last) {
+    try {                                               // (host copies of the transfers' patterns: no exception leaves the C ABI)
+        return push_level_impl(s, n_fine, n_coarse, p_indptr, p_indices, p_vals, r_indptr, r_indices, r_vals, a_indptr, a_indices,
+                               a_vals, d_indptr, d_indices, d_vals, omega_fine, last);
+    } catch (const std::bad_alloc&) {
+        return FEP_ENOMEM;
+    } catch (...) {
+        return FEP_EINVAL;
+    }
+}
+
+static int push_level_impl(fep_solver* s, int64_t n_fine, int64_t n_coarse,
+                           const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
+                           const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,
+                           const int32_t* a_indptr, const int32_t* a_indices, const double* a_vals,
+                           const int32_t* d_indptr, const int32_t* d_indices, const double* d_vals,
+                           double omega_fine, int last) {
     if (!s || n_fine <= 0 || n_coarse <= 0 || !(omega_fine > 0.0)) return FEP_EINVAL;
     if (!s->levels.empty() && (s->levels.back().last || s->levels.back().n_coarse != n_fine)) return FEP_ESTATE;
     if (s->levels.empty() && n_fine != s->n_dof) return FEP_EINVAL;
@@ -650,7 +852,13 @@ extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t 
     fep_solver::Level& l = s->levels.back();
     l.n_fine = n_fine; l.n_coarse = n_coarse; l.omega = omega_fine; l.last = last != 0;
     int rc = upload_csr(l.P, n_fine, n_coarse, p_indptr, p_indices, p_vals);
+    if (rc == FEP_OK) {
+        l.hPp.assign(p_indptr, p_indptr + n_fine + 1); l.hPi.assign(p_indices, p_indices + p_indptr[n_fine]);
+    }
     if (rc == FEP_OK) rc = upload_csr(l.R, n_coarse, n_fine, r_indptr, r_indices, r_vals);
+    if (rc == FEP_OK) {
+        l.hRp.assign(r_indptr, r_indptr + n_coarse + 1); l.hRi.assign(r_indices, r_indices + r_indptr[n_coarse]);
+    }
     if (rc == FEP_OK) rc = upload_csr(l.A, n_coarse, n_coarse, a_indptr, a_indices, a_vals);
     if (rc == FEP_OK && !last) rc = upload_csr(l.D, n_coarse, n_coarse, d_indptr, d_indices, d_vals);
     for (double** v : {&l.x, &l.b, &l.r, &l.t})
@@ -660,7 +868,8 @@ extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t 
         }
     if (rc == FEP_OK && !s->t0) {
         if (hipMalloc((void**)&s->t0, (size_t)s->n_dof * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&s->q, (size_t)s->n_dof * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
+            hipMalloc((void**)&s->q, (size_t)s->n_dof * sizeof(double)) != hipSuccess ||
+            (s->fp32 && hipMalloc((void**)&s->k32, (size_t)s->n_blk * 4 * sizeof(float)) != hipSuccess)) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
     }
     if (rc != FEP_OK) {
         fep_solver::Level& b = s->levels.back();
@@ -671,19 +880,180 @@ extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t 
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------
+// Coarse operators of the CURRENT tangent.  The hierarchy's transfers stay those of the reference matrix; with the refresh
+// enabled every multigrid solve first forms A_1 = R_0 K P_0, A_2 = R_1 A_1 P_1, ... from its own K (numeric products on
+// patterns fixed at set-up: fep_host.h product_plan), the 3x3 block-Jacobi inverses of the new operators and the dense
+// inverse of the coarsest one.  On the tangents of the strip-footing run this takes a third off the iteration counts
+// (tools/deflation_study.py; operators one Newton iterate old are worse than those of the elastic matrix).
+// Constrained DOFs need no masking: their rows of P (columns of R) are zero.
+// ---------------------------------------------------------------------------------------
+static int enable_refresh_impl(fep_solver* s) {
+    if (s->levels.empty() || !s->levels.back().last) return FEP_ESTATE;
+    if (s->refresh) return FEP_OK;
+    if (s->levels.back().n_coarse > kDenseMax) return FEP_ERANGE;          // (nothing touched: the hierarchy stays usable)
+    FEP_TRY(fep_set_device(s->device));
+    // 1. everything on the host first: patterns of A_k P_k and of R_k (A_k P_k), the terms of both products
+    struct HostLevel { std::vector<int32_t> Ap, Ai, d9, nbp, nbc; fep_host::ProductPlan ap, rt; size_t nT = 0; };
+    std::vector<HostLevel> H(s->levels.size());
+    std::vector<int32_t> Xp = s->ip0, Xi = s->ix0;                       // pattern of the operator of level k
+    for (size_t k = 0; k < s->levels.size(); ++k) {
+        const fep_solver::Level& l = s->levels[k];
+        HostLevel& h = H[k];
+        std::vector<int32_t> Tp, Ti;
+        FEP_TRY(fep_host::product_pattern(l.n_fine, l.n_fine, l.n_coarse, Xp.data(), Xi.data(), l.hPp.data(), l.hPi.data(), Tp, Ti));
+        FEP_TRY(fep_host::product_plan(l.n_fine, l.n_fine, Xp.data(), Xi.data(), l.hPp.data(), l.hPi.data(), Tp.data(), Ti.data(), 0, h.ap));
+        h.nT = Ti.size();
+        if (l.last) {                                                    // the coarsest operator is dense (it is inverted)
+            FEP_TRY(fep_host::product_plan(l.n_coarse, l.n_fine, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), nullptr, nullptr, l.n_coarse, h.rt));
+            h.Ap.resize((size_t)l.n_coarse + 1); h.Ai.resize((size_t)(l.n_coarse * l.n_coarse));
+            for (int64_t i = 0; i <= l.n_coarse; ++i) h.Ap[(size_t)i] = (int32_t)(i * l.n_coarse);
+            for (int64_t i = 0; i < l.n_coarse * l.n_coarse; ++i) h.Ai[(size_t)i] = (int32_t)(i % l.n_coarse);
+        } else {
+            if (l.n_coarse % 3 || l.D.nnz != 3 * l.n_coarse) return FEP_EINVAL;
+            // the operator of level k+1 moves onto the pattern of the product (SciPy's may have dropped entries)
+            FEP_TRY(fep_host::product_pattern(l.n_coarse, l.n_fine, l.n_coarse, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), h.Ap, h.Ai));
+            // padded to whole 3x3 node blocks, the three rows of a node on the same block columns (node3_kernel)
+            {
+                const int64_t nn = l.n_coarse / 3;
+                std::vector<int32_t> Ap2((size_t)l.n_coarse + 1, 0), Ai2, cols;
+                h.nbp.assign((size_t)nn + 1, 0);
+                for (int64_t I = 0; I < nn; ++I) {
+                    cols.clear();
+                    for (int32_t t = h.Ap[(size_t)(3 * I)]; t < h.Ap[(size_t)(3 * I + 3)]; ++t) cols.push_back(h.Ai[(size_t)t] / 3);
+                    std::sort(cols.begin(), cols.end());
+                    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+                    h.nbc.insert(h.nbc.end(), cols.begin(), cols.end());
+                    if (h.nbc.size() * 9 >= (size_t)INT32_MAX) return FEP_ERANGE;
+                    h.nbp[(size_t)I + 1] = (int32_t)h.nbc.size();
+                    for (int a = 0; a < 3; ++a) {
+                        for (int32_t J : cols) { Ai2.push_back(3 * J); Ai2.push_back(3 * J + 1); Ai2.push_back(3 * J + 2); }
+                        Ap2[(size_t)(3 * I + a + 1)] = (int32_t)Ai2.size();
+                    }
+                }
+                h.Ap.swap(Ap2); h.Ai.swap(Ai2);
+            }
+            FEP_TRY(fep_host::product_plan(l.n_coarse, l.n_fine, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), h.Ap.data(), h.Ai.data(), 0, h.rt));
+            h.d9.assign((size_t)l.n_coarse * 3, -1);
+            for (int64_t r = 0; r < l.n_coarse; ++r) {
+                const int64_t c0 = r - r % 3;
+                for (int32_t t = h.Ap[(size_t)r]; t < h.Ap[(size_t)r + 1]; ++t)
+                    if (h.Ai[(size_t)t] >= c0 && h.Ai[(size_t)t] < c0 + 3) h.d9[(size_t)(3 * r + (h.Ai[(size_t)t] - c0))] = t;
+            }
+        }
+        Xp = h.Ap; Xi = h.Ai;
+    }
+    // 2. onto the device; a failure here leaves no half-converted hierarchy behind: it is dropped
+    int rc = FEP_OK;
+    auto up = [&](int32_t** dst, const std::vector<int32_t>& v) {
+        if (rc != FEP_OK) return;
+        hipError_t e = hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(int32_t));
+        if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; }
+    };
+    // the constant factor's value goes into the term (composed on the device from the index pairs)
+    auto up_plan = [&](fep_solver::Plan& d, const fep_host::ProductPlan& h, const double* cv_d, bool first) {
+        d.n_out = (int64_t)h.tptr.size() - 1;
+        up(&d.tptr, h.tptr);
+        int32_t *xa = nullptr, *ya = nullptr;
+        up(&xa, h.xa); up(&ya, h.ya);
+        const int64_t n = (int64_t)h.xa.size();
+        if (rc == FEP_OK && hipMalloc(&d.terms, std::max<size_t>((size_t)n, 1) * sizeof(Term)) != hipSuccess) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
+        if (rc == FEP_OK && n > 0) {
+            hipLaunchKernelGGL(compose_terms_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, 0, n, xa, ya, cv_d, first ? 1 : 0, (Term*)d.terms);
+            if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); rc = FEP_EHIP; }
+        }
+        if (xa) (void)hipFree(xa);
+        if (ya) (void)hipFree(ya);
+    };
+    auto dalloc = [&](double** dst, size_t n) {
+        if (rc == FEP_OK && hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
+    };
+    for (size_t k = 0; k < s->levels.size(); ++k) {
+        fep_solver::Level& l = s->levels[k];
+        const HostLevel& h = H[k];
+        free_csr(l.A);
+        l.A.n_rows = l.n_coarse; l.A.nnz = (int64_t)h.Ai.size();
+        up(&l.A.indptr, h.Ap); up(&l.A.indices, h.Ai);
+        dalloc(&l.A.vals, h.Ai.size()); dalloc(&l.T, h.nT);
+        up_plan(l.ap, h.ap, l.P.vals, false); up_plan(l.rt, h.rt, l.R.vals, true);
+        if (!l.last) { up(&l.d9, h.d9); up(&l.nbp, h.nbp); up(&l.nbc, h.nbc); }
+    }
+    if (rc != FEP_OK) { free_levels(s); return rc; }
+    if (std::getenv("FEP_VERBOSE")) {
+        std::fprintf(stderr, "[fep] multigrid refresh plans:");
+        for (size_t k = 0; k < s->levels.size(); ++k)
+            std::fprintf(stderr, " %lld -> %lld DOFs (A P: %lld entries, %zu terms; R (A P): %lld, %zu)", (long long)s->levels[k].n_fine,
+                         (long long)s->levels[k].n_coarse, (long long)s->levels[k].ap.n_out, H[k].ap.xa.size(),
+                         (long long)s->levels[k].rt.n_out, H[k].rt.xa.size());
+        std::fprintf(stderr, "\n");
+    }
+    s->refresh = true;
+    return FEP_OK;
+}
+
+extern "C" int fep_solver_amg_enable_refresh(fep_solver* s) {
+    if (!s) return FEP_EINVAL;
+    try {
+        return enable_refresh_impl(s);
+    } catch (const std::bad_alloc&) {
+        return FEP_ENOMEM;
+    } catch (...) {
+        return FEP_EINVAL;
+    }
+}
+
+extern "C" int fep_solver_amg_refresh_dev(fep_solver* s, void* stream, const double* k_data_d) {
+    if (!s || !k_data_d) return FEP_EINVAL;
+    if (!s->refresh) return FEP_ESTATE;
+    FEP_TRY(fep_set_device(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double* A = k_data_d;
+    for (fep_solver::Level& l : s->levels) {
+        hipLaunchKernelGGL(product_kernel, dim3((unsigned)((l.ap.n_out + TPB - 1) / TPB)), dim3(TPB), 0, st, l.ap.n_out,
+                           l.ap.tptr, (const Term*)l.ap.terms, A, l.T);
+        hipLaunchKernelGGL(product_kernel, dim3((unsigned)((l.rt.n_out + TPB - 1) / TPB)), dim3(TPB), 0, st, l.rt.n_out,
+                           l.rt.tptr, (const Term*)l.rt.terms, (const double*)l.T, l.A.vals);
+        if (l.last)
+            hipLaunchKernelGGL(dense_inverse_kernel, dim3(1), dim3(1024), 0, st, (int)l.n_coarse, l.A.vals);
+        else
+            hipLaunchKernelGGL(block3_inverse_kernel, dim3((unsigned)((l.n_coarse / 3 + TPB - 1) / TPB)), dim3(TPB), 0, st,
+                               l.n_coarse / 3, l.d9, l.A.vals, l.D.vals);
+        A = l.A.vals;
+    }
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
 namespace {
 
 inline void csr_apply(hipStream_t st, const fep_solver::Csr& m, const double* x, const double* z, double c0, double c1,
                       double* y) {
-    const unsigned grid = (unsigned)((m.n_rows * 8 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(csr_kernel<false>, dim3(grid), dim3(TPB), 0, st, m.n_rows, m.indptr, m.indices, m.vals, x, z, c0, c1, y,
-                       (const double*)nullptr, 0.0);
+    if (m.nnz < 12 * m.n_rows)
+        hipLaunchKernelGGL((csr_kernel<false, 2>), dim3((unsigned)((m.n_rows * 2 + TPB - 1) / TPB)), dim3(TPB), 0, st, m.n_rows, m.indptr,
+                           m.indices, m.vals, x, z, c0, c1, y, (const double*)nullptr, 0.0);
+    else
+        hipLaunchKernelGGL((csr_kernel<false, 8>), dim3((unsigned)((m.n_rows * 8 + TPB - 1) / TPB)), dim3(TPB), 0, st, m.n_rows, m.indptr,
+                           m.indices, m.vals, x, z, c0, c1, y, (const double*)nullptr, 0.0);
 }
 
 inline void csr_apply2(hipStream_t st, const fep_solver::Csr& m, const double* x, const double* z, double c0, const double* z2,
                        double c2, double c1, double* y) {
     const unsigned grid = (unsigned)((m.n_rows * 8 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(csr_kernel<true>, dim3(grid), dim3(TPB), 0, st, m.n_rows, m.indptr, m.indices, m.vals, x, z, c0, c1, y, z2, c2);
+    hipLaunchKernelGGL((csr_kernel<true, 8>), dim3(grid), dim3(TPB), 0, st, m.n_rows, m.indptr, m.indices, m.vals, x, z, c0, c1, y, z2, c2);
+}
+
+// one level-0 pass of the V-cycle (block_residual_kernel) on the solve's K — its single-precision copy when there is one
+template <int SMOOTH>
+inline void block_pass(fep_solver* s, hipStream_t st, const double* K, const double* x, const double* b, double omega, double* out,
+                       double ca, double cprev, const double* xprev) {
+    const dim3 gm(s->n_mv_blocks), tb(TPB);
+    if (s->fp32 && s->k32)
+        hipLaunchKernelGGL((block_residual_kernel<SMOOTH, float2>), gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof,
+                           (const float2*)s->k32, (const double2*)x, b, s->minv, omega, out, ca, cprev, (const double2*)xprev);
+    else
+        hipLaunchKernelGGL((block_residual_kernel<SMOOTH, double2>), gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof,
+                           (const double2*)K, (const double2*)x, b, s->minv, omega, out, ca, cprev, (const double2*)xprev);
 }
 
 // Degree-2 Chebyshev smoother for D^-1 A on [lmax / alpha, lmax], lmax = safety * (largest eigenvalue the hierarchy was
@@ -704,18 +1074,15 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
 
 double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0) {
     if (s->cheb) return vcycle_chebyshev(s, st, K, b0);
-    const dim3 gv(s->n_vec_blocks), gm(s->n_mv_blocks), tb(TPB);
-    const double2* K2 = (const double2*)K;
+    const dim3 gv(s->n_vec_blocks), tb(TPB);
     std::vector<fep_solver::Level>& L = s->levels;
     const int nl = (int)L.size();
     double *xa = s->u, *xb = s->w;
     const double w0 = L[0].omega;
     // level 0, pre-smoothing from x = 0
     hipLaunchKernelGGL(block_scale_kernel, gv, tb, 0, st, s->n_n, s->free_dof, s->minv, (const double2*)b0, w0, (double2*)xa);
-    hipLaunchKernelGGL(block_residual_kernel<1>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xa, b0, s->minv, w0, xb, 1.0, 0.0, (const double2*)nullptr);
-    hipLaunchKernelGGL(block_residual_kernel<0>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xb, b0, s->minv, 0.0, s->t0, 1.0, 0.0, (const double2*)nullptr);
+    block_pass<1>(s, st, K, xa, b0, w0, xb, 1.0, 0.0, nullptr);
+    block_pass<0>(s, st, K, xb, b0, 0.0, s->t0, 1.0, 0.0, nullptr);
     csr_apply(st, L[0].R, s->t0, nullptr, 0.0, 1.0, L[0].b);
     // coarse levels down: level k+1 lives in L[k].{A, D, x, b, r}; its smoother weight is L[k+1].omega
     for (int k = 0; k + 1 < nl; ++k) {
@@ -740,10 +1107,8 @@ double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0)
         }
     }
     csr_apply(st, L[0].P, L[0].x, xb, 1.0, 1.0, xb);
-    hipLaunchKernelGGL(block_residual_kernel<1>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xb, b0, s->minv, w0, xa, 1.0, 0.0, (const double2*)nullptr);
-    hipLaunchKernelGGL(block_residual_kernel<1>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xa, b0, s->minv, w0, xb, 1.0, 0.0, (const double2*)nullptr);
+    block_pass<1>(s, st, K, xb, b0, w0, xa, 1.0, 0.0, nullptr);
+    block_pass<1>(s, st, K, xa, b0, w0, xb, 1.0, 0.0, nullptr);
     return xb;
 }
 
@@ -752,43 +1117,64 @@ double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0)
 // symmetric positive definite operator as long as lmax bounds the spectrum (safety factor 1.2 on the estimate the
 // hierarchy was built with; a tangent's own largest eigenvalue measured 3.5 % above its elastic matrix's).
 double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const double* b0) {
-    const dim3 gv(s->n_vec_blocks), gm(s->n_mv_blocks), tb(TPB);
-    const double2* K2 = (const double2*)K;
+    const dim3 gv(s->n_vec_blocks), tb(TPB);
     std::vector<fep_solver::Level>& L = s->levels;
     const int nl = (int)L.size();
     double *xa = s->u, *xb = s->w;
     const Cheb c0 = cheb_coefficients(L[0].omega, s->cheb_alpha, s->cheb_safety);
     // level 0, pre-smoothing from x = 0: x1 = c1 D^-1 b, x2 = a2 x1 + w2 D^-1 (b - K x1)
     hipLaunchKernelGGL(block_scale_kernel, gv, tb, 0, st, s->n_n, s->free_dof, s->minv, (const double2*)b0, c0.c1, (double2*)xa);
-    hipLaunchKernelGGL(block_residual_kernel<2>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xa, b0, s->minv, c0.w2, xb, c0.a2, 0.0, (const double2*)nullptr);
-    hipLaunchKernelGGL(block_residual_kernel<0>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xb, b0, s->minv, 0.0, s->t0, 1.0, 0.0, (const double2*)nullptr);
+    block_pass<2>(s, st, K, xa, b0, c0.w2, xb, c0.a2, 0.0, nullptr);
+    block_pass<0>(s, st, K, xb, b0, 0.0, s->t0, 1.0, 0.0, nullptr);
     csr_apply(st, L[0].R, s->t0, nullptr, 0.0, 1.0, L[0].b);
+    // with the refresh the coarse operators sit on whole 3x3 node blocks: node3_kernel does an operator pass and the
+    // block-Jacobi step behind it in one launch (7 launches per level and cycle instead of 10)
+    const bool n3 = s->refresh;
+    auto node3 = [&](int mode, const fep_solver::Level& c, const double* x, double om, double ca, double cp, const double* xp,
+                     double* out) {
+        const int64_t nn = c.n_coarse / 3;
+        const dim3 g((unsigned)((nn + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK));
+        if (mode == 0) hipLaunchKernelGGL(node3_kernel<0>, g, tb, 0, st, nn, c.nbp, c.nbc, c.A.vals, c.D.vals, x, c.b, om, ca, cp, xp, out);
+        else if (mode == 1) hipLaunchKernelGGL(node3_kernel<1>, g, tb, 0, st, nn, c.nbp, c.nbc, c.A.vals, c.D.vals, x, c.b, om, ca, cp, xp, out);
+        else hipLaunchKernelGGL(node3_kernel<2>, g, tb, 0, st, nn, c.nbp, c.nbc, c.A.vals, c.D.vals, x, c.b, om, ca, cp, xp, out);
+    };
     for (int k = 0; k + 1 < nl; ++k) {
         fep_solver::Level& c = L[k];
         const Cheb ch = cheb_coefficients(L[k + 1].omega, s->cheb_alpha, s->cheb_safety);
         csr_apply(st, c.D, c.b, nullptr, 0.0, ch.c1, c.x);           // x1 = c1 D b
-        csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);                // r1 = b - A x1
-        csr_apply(st, c.D, c.r, c.x, ch.a2, ch.w2, c.x);             // x2 = a2 x1 + w2 D r1
-        csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
+        if (n3) {
+            node3(2, c, c.x, ch.w2, ch.a2, 0.0, nullptr, c.t);       // x2 = a2 x1 + w2 D (b - A x1)
+            node3(0, c, c.t, 0.0, 0.0, 0.0, nullptr, c.r);           // r = b - A x2
+            c.xcur = c.t;
+        } else {
+            csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);            // r1 = b - A x1
+            csr_apply(st, c.D, c.r, c.x, ch.a2, ch.w2, c.x);         // x2 = a2 x1 + w2 D r1
+            csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
+            c.xcur = c.x;
+        }
         csr_apply(st, L[k + 1].R, c.r, nullptr, 0.0, 1.0, L[k + 1].b);
     }
     csr_apply(st, L[nl - 1].A, L[nl - 1].b, nullptr, 0.0, 1.0, L[nl - 1].x);
+    L[nl - 1].xcur = L[nl - 1].x;
     for (int k = nl - 2; k >= 0; --k) {
         fep_solver::Level& c = L[k];
         const Cheb ch = cheb_coefficients(L[k + 1].omega, s->cheb_alpha, s->cheb_safety);
-        csr_apply(st, L[k + 1].P, L[k + 1].x, c.x, 1.0, 1.0, c.x);   // x0 = x + P x_coarse
-        csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);                // r0
-        csr_apply(st, c.D, c.r, c.x, 1.0, ch.c1, c.t);               // x1 = x0 + c1 D r0        (x0 stays in c.x)
-        csr_apply(st, c.A, c.t, c.b, 1.0, -1.0, c.r);                // r1
-        csr_apply2(st, c.D, c.r, c.t, ch.a2, c.x, ch.cp, ch.w2, c.x);   // x2 = a2 x1 + cp x0 + w2 D r1
+        csr_apply(st, L[k + 1].P, L[k + 1].xcur, c.xcur, 1.0, 1.0, c.xcur);   // x0 = x + P x_coarse
+        if (n3) {
+            double* x1 = c.xcur == c.t ? c.x : c.t;
+            node3(1, c, c.xcur, ch.c1, 1.0, 0.0, nullptr, x1);       // x1 = x0 + c1 D (b - A x0)
+            node3(2, c, x1, ch.w2, ch.a2, ch.cp, c.xcur, c.r);       // x2 = a2 x1 + cp x0 + w2 D (b - A x1)
+            c.xcur = c.r;
+        } else {
+            csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);            // r0
+            csr_apply(st, c.D, c.r, c.x, 1.0, ch.c1, c.t);           // x1 = x0 + c1 D r0        (x0 stays in c.x)
+            csr_apply(st, c.A, c.t, c.b, 1.0, -1.0, c.r);            // r1
+            csr_apply2(st, c.D, c.r, c.t, ch.a2, c.x, ch.cp, ch.w2, c.x);   // x2 = a2 x1 + cp x0 + w2 D r1
+        }
     }
-    csr_apply(st, L[0].P, L[0].x, xb, 1.0, 1.0, xb);                 // x0
-    hipLaunchKernelGGL(block_residual_kernel<1>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xb, b0, s->minv, c0.c1, xa, 1.0, 0.0, (const double2*)nullptr);   // x1 = x0 + c1 D^-1 r0
-    hipLaunchKernelGGL(block_residual_kernel<2>, gm, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, K2,
-                       (const double2*)xa, b0, s->minv, c0.w2, s->t0, c0.a2, c0.cp, (const double2*)xb);  // x2 -> t0
+    csr_apply(st, L[0].P, L[0].xcur, xb, 1.0, 1.0, xb);              // x0
+    block_pass<1>(s, st, K, xb, b0, c0.c1, xa, 1.0, 0.0, nullptr);   // x1 = x0 + c1 D^-1 r0
+    block_pass<2>(s, st, K, xa, b0, c0.w2, s->t0, c0.a2, c0.cp, xb);  // x2 -> t0
     return s->t0;
 }
 
@@ -806,6 +1192,10 @@ extern "C" int fep_solver_amg_pcg_dev(fep_solver* s, void* stream, const double*
     const dim3 gv(s->n_vec_blocks), gm(s->n_mv_blocks), tb(TPB), one(1), big(1024);
     const double tol2 = rtol * rtol;
     double2 *x = (double2*)x_d, *r = (double2*)s->r, *p = (double2*)s->p;
+    if (s->refresh) FEP_TRY(fep_solver_amg_refresh_dev(s, stream, k_data_d));
+    if (s->fp32 && s->k32)
+        hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((s->n_blk + TPB - 1) / TPB)), tb, 0, st, s->n_blk, (const double4*)k_data_d,
+                           (float4*)s->k32);
     hipLaunchKernelGGL(block_jacobi_kernel, gv, tb, 0, st, s->n_n, s->nptr, s->ncol, s->free_dof, k_data_d, s->minv);
     hipLaunchKernelGGL(mg_init_kernel, gv, tb, 0, st, s->n_n, (const double2*)b_d, s->free_dof, x, r, s->part_r);
     double* z = vcycle(s, st, k_data_d, s->r);

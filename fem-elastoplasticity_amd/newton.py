@@ -22,6 +22,8 @@ states are the same to the Newton tolerance either way.
 `transform` (DP:760-816, nodal averaging used for the footing pressure that steers the step size) is re-stated
 with `np.bincount` on the host and as `fep_transform_dev` on the device.
 """
+import time
+
 import numpy as np
 import scipy.sparse.linalg as sspl
 
@@ -199,7 +201,9 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     bulk0 = young / (3 * (1 - 2 * poisson))
     eta0 = 3 * np.tan(phi) / np.sqrt(9 + 12 * (np.tan(phi)) ** 2)
     c_0 = 3 * c0 / np.sqrt(9 + 12 * (np.tan(phi)) ** 2)
+    t_setup = [time.perf_counter()]
     mesh = square_mesh(size_xy * 2 ** level if n_cells is None else n_cells, t, size_xy)  # DP:945
+    t_setup.append(time.perf_counter())
     elem, coord, Q = mesh['elements'], mesh['coordinates'], mesh['Q']
     q_nd = mesh['dirichlet_nodes'][1, :] > 0
     n_n = coord.shape[1]
@@ -207,11 +211,17 @@ def solve_strip_footing(element_type='P1', level=1, n_cells=None, size_xy=10, ma
     ctx = (context_factory or (lambda *a: MeshContext(*a, device=device)))(elem, coord, d1, d2, wf)
     ctx.set_materials(shear0, bulk0, eta0, c_0)
     qf = Q.flatten(order='F')
+    t_setup.append(time.perf_counter())
     ops = (_ops_factory or _make_ops)(ctx, qf, linear_solver, pcg_rtol, pcg_forcing, pcg_forcing_cap, pcg_inexact_rtol)
     K_elast = ops.step(ops.zeros(), want=('K',), keep_K=True)['K']                        # DP:977
+    t_setup.append(time.perf_counter())
     if linear_solver == 'amg':
         ops.setup_amg(K_elast, coord)
     _, _, weight, _ = ctx.geometry()
+    t_setup.append(time.perf_counter())
+    if log:
+        log('setup: mesh %.2f s, context %.2f s, solver + K_elast %.2f s, multigrid hierarchy %.2f s'
+            % tuple(b - a for a, b in zip(t_setup[:-1], t_setup[1:])))
 
     d_zeta = 1 / 1000                                                                     # DP:989-994
     d_zeta_min = d_zeta / 1300

@@ -9,10 +9,14 @@ Two preconditioners: the 2x2 node-block Jacobi that is always there, and a smoot
 (`setup_amg`): aggregates of the node graph, tentative prolongators from the rigid-body modes (two translations and
 the rotation, 3 DOFs per aggregate), one damped-Jacobi smoothing step of the prolongator, Galerkin coarse operators.
 The hierarchy is built once per mesh on the host with SciPy from a reference matrix (K_elast) and lives on the GPU;
-every solve smooths with the CURRENT tangent on the mesh level and keeps the coarse operators of the reference
-matrix (a tangent that softens in the plastic zone costs ~20 % more iterations than its own hierarchy would).
+every solve smooths with the CURRENT tangent on the mesh level and — `refresh`, the default — re-projects the coarse
+operators from that tangent with the transfers of the reference matrix (numeric Galerkin products on the GPU; a third
+fewer iterations on plastic tangents than with the reference matrix's coarse operators).
 """
 import ctypes as C
+import os
+import sys
+import time
 
 import numpy as np
 import scipy.sparse as ssp
@@ -190,15 +194,23 @@ class KrylovSolver:
             raise ValueError(f'expected {n} contiguous float64 values')
         return v
 
-    def setup_amg(self, K_ref, coordinates, coarse_nodes=400, max_levels=8):
+    def setup_amg(self, K_ref, coordinates, coarse_nodes=400, max_levels=8, refresh=None):
         """Builds the multigrid hierarchy from `K_ref` (csr_matrix on the pattern, or its data array; host) and the
-        node coordinates (2, n_n), and loads it onto the device.  Returns [(DOFs, nnz)] per level."""
+        node coordinates (2, n_n), and loads it onto the device.  Returns [(DOFs, nnz)] per level.
+        `refresh` (default: on unless FEP_AMG_REFRESH=0): every solve re-projects the coarse operators from its own
+        tangent with the transfers built here (fep_solver_amg_enable_refresh); `self.amg_refresh` tells whether it is on."""
         if not hasattr(self, '_pattern'):
             raise ValueError('setup_amg needs the solver to have been created from a pattern')
         ip, ix = self._pattern
         data = K_ref.data if hasattr(K_ref, 'indptr') else np.asarray(K_ref, dtype=np.float64)
         K = ssp.csr_matrix((data, ix, ip), shape=(self.n_dof, self.n_dof))
+        if refresh is None:
+            refresh = os.environ.get('FEP_AMG_REFRESH', '1') != '0'
+        if refresh:                                      # the coarsest operator is re-inverted by every solve: keep it small
+            coarse_nodes = min(coarse_nodes, 64)
+        t0 = time.perf_counter()
         levels = build_amg_hierarchy(K, self.free_dof, coordinates, coarse_nodes, max_levels)
+        t1 = time.perf_counter()
         l = _lib.lib()
         _lib.check(l.fep_solver_amg_clear(self._h), 'fep_solver_amg_clear')
         for lv in levels:
@@ -212,6 +224,16 @@ class KrylovSolver:
             _lib.check(l.fep_solver_amg_push_level(self._h, lv['P'].shape[0], lv['P'].shape[1], *[_lib.ptr(m) for m in mats],
                                                    float(lv['omega']), int(lv['last'])), 'fep_solver_amg_push_level')
         self.amg_levels = [(K.shape[0], K.nnz)] + [lv['size'] for lv in levels]
+        self.amg_refresh = False
+        t2 = time.perf_counter()
+        if refresh:
+            rc = l.fep_solver_amg_enable_refresh(self._h)
+            if rc != -5:                                 # FEP_ERANGE: too large a coarsest level / product: the operators of K_ref stay
+                _lib.check(rc, 'fep_solver_amg_enable_refresh')
+                self.amg_refresh = True
+        self.amg_seconds = {'hierarchy': t1 - t0, 'upload': t2 - t1, 'refresh_plans': time.perf_counter() - t2}
+        if os.environ.get('FEP_VERBOSE'):
+            print('[fep] multigrid set-up: ' + ', '.join(f'{k} {v:.2f} s' for k, v in self.amg_seconds.items()), file=sys.stderr)
         return self.amg_levels
 
     def spmv(self, k_data, x, out=None, masked=False):

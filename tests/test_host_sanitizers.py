@@ -86,6 +86,8 @@ def test_host_native_code_under_sanitizers(fep, binaries, tmp_path, kind):
                 assert res.stdout.count(': rc 0 check 0 tiles') == 11, res.stdout  # 4 raw tilings + 7 plan variants, all validated
             # the element route's patch plans: 3 patch sizes x 4 groupings, each replayed against the symbolic phase
             assert len([l for l in res.stdout.splitlines() if l.startswith('patch plan') and ' ok 1 check 0 ' in l]) == 12, res.stdout
+            # the multigrid refresh's sparse products on fixed patterns, against the triple loop
+            assert 'product plans: rc 0 terms' in res.stdout, res.stdout
 
 
 def test_two_row_tiles_stage_fewer_elements_on_a_row_numbered_mesh(fep, binaries, tmp_path):

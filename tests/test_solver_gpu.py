@@ -120,6 +120,34 @@ def test_multigrid_pcg_matches_sparse_direct(fep, et, n):
     ctx.close()
 
 
+@pytest.mark.parametrize('et,n', [('P1', 64), ('P2', 16), ('Q1', 32)])
+def test_multigrid_refresh_reprojects_the_coarse_operators(fep, et, n):
+    """`setup_amg(..., refresh=True)` (the default): every solve forms its coarse operators from ITS matrix with the
+    transfers of the reference matrix (numeric Galerkin products on the device).  For the reference matrix itself these are
+    the operators SciPy built at set-up, so the iteration counts agree; on a plastic tangent the solve needs fewer
+    iterations than with the stale operators and reaches the same solution; run-to-run bitwise reproducible."""
+    mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
+    K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
+    b = rng.normal(size=ctx.n_dof)
+    res = {}
+    for refresh in (False, True):
+        sol = fep.KrylovSolver(ctx, qf)
+        sol.setup_amg(K_el, mesh['coordinates'], coarse_nodes=30, refresh=refresh)
+        assert sol.amg_refresh is refresh
+        for name, K in (('elastic', K_el), ('tangent', r['K'])):
+            x = sol.solve_host(K, b, rtol=1e-11)
+            assert sol.last['state'] == 1
+            assert np.linalg.norm((K @ x - b)[qf]) <= 1e-9 * np.linalg.norm(b[qf])
+            assert np.array_equal(x, sol.solve_host(K, b, rtol=1e-11))
+            res[refresh, name] = (x, sol.last['iters'])
+        sol.close()
+    assert abs(res[True, 'elastic'][1] - res[False, 'elastic'][1]) <= 1
+    assert relerr(res[True, 'elastic'][0], res[False, 'elastic'][0]) <= 1e-8
+    assert res[True, 'tangent'][1] <= res[False, 'tangent'][1]
+    assert relerr(res[True, 'tangent'][0], res[False, 'tangent'][0]) <= 1e-7
+    ctx.close()
+
+
 def test_drivers_with_multigrid_solver(fep):
     from conftest import load_golden
     g = load_golden('dp_p1_level1_trace')
