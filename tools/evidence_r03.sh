@@ -19,6 +19,9 @@ for t in "P2 708" "Q2 708" "Q1 708" "P4 354"; do for v in "FEP_GEN_PATH=patch" "
 for v in "FEP_GEN_PATH=patch" "FEP_GEN_PATH=coo"; do echo "== P2 708 K,F-only $v" >> $out/elem_bench.log; env $v python tools/elem_bench.py P2 708 30 bands kf 2>&1 | grep -v amdgpu.ids >> $out/elem_bench.log; echo "== P2 1414 random $v" >> $out/elem_bench.log; env $v python tools/elem_bench.py P2 1414 10 random 2>&1 | grep -v amdgpu.ids >> $out/elem_bench.log; done
 python tools/setup_bench.py > $out/setup_bench.log 2>&1
 python tools/host_path_bench.py > $out/host_path.log 2>&1
-python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end.log 2>&1; echo "newton rc=$?"
+for v in "FEP_PATCH_TPB=256"; do echo "== P2 708 $v" >> $out/elem_bench.log; env $v python tools/elem_bench.py P2 708 30 2>&1 | grep -v amdgpu.ids >> $out/elem_bench.log; echo "== P2 1414 random $v" >> $out/elem_bench.log; env $v python tools/elem_bench.py P2 1414 10 random 2>&1 | grep -v amdgpu.ids >> $out/elem_bench.log; done
+FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end.log 2>&1; echo "newton rc=$?"
+FEP_AMG_REFRESH=0 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end_elastic_coarse.log 2>&1; echo "newton (elastic coarse operators) rc=$?"
+TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_nb -- python3 tools/newton_bench.py --inexact 1e-2 --steps 2 > $out/prof_newton.log 2>&1; find /tmp/prof_nb -name "*kernel_stats.csv" -exec cp {} $out/newton_kernel_stats.csv \;
 rocm-smi --showclocks --showpower > $out/rocm_smi_after.txt 2>&1
 tail -4 $out/prof_p1.log; tail -4 $out/prof_p2.log; tail -3 $out/prof_p4.log; cut -c1-700 $out/bench_n1.json; cat $out/bench_n1.err | tail -2; tail -1 $out/newton_end_to_end.log | cut -c1-300
