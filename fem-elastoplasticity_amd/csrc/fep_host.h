@@ -1327,6 +1327,7 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
 }
 
 // Greedy aggregation of a node graph in CSR (smoothed-aggregation multigrid setup): agg_out[i] in [0, *n_agg_out).
+// A node's neighbour list may hold an id more than once and in any order (solver.py passes the rows of a node's DOFs back to back).
 inline int aggregate(int64_t n, const int32_t* indptr, const int32_t* indices, int32_t* agg_out, int64_t* n_agg_out) {
     if (n <= 0 || !indptr || !indices || !agg_out || !n_agg_out) return FEP_EINVAL;
     std::vector<int32_t> agg((size_t)n, -1);
@@ -1345,12 +1346,13 @@ inline int aggregate(int64_t n, const int32_t* indptr, const int32_t* indices, i
     std::vector<int32_t> fin(agg);
     for (int64_t i = 0; i < n; ++i) {
         if (agg[i] >= 0) continue;
-        int32_t a = -1;
-        for (int32_t t = indptr[i]; t < indptr[i + 1] && a < 0; ++t) {
-            if (indices[t] < 0 || indices[t] >= n) return FEP_ERANGE;
-            a = agg[indices[t]];
+        int32_t jmin = -1;                               // the aggregated neighbour of smallest id: the list may repeat ids, in any order
+        for (int32_t t = indptr[i]; t < indptr[i + 1]; ++t) {
+            const int32_t j = indices[t];
+            if (j < 0 || j >= n) return FEP_ERANGE;
+            if (agg[j] >= 0 && (jmin < 0 || j < jmin)) jmin = j;
         }
-        fin[i] = a >= 0 ? a : na++;
+        fin[i] = jmin >= 0 ? agg[jmin] : na++;
     }
     std::memcpy(agg_out, fin.data(), (size_t)n * sizeof(int32_t));
     *n_agg_out = na;

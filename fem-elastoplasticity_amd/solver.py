@@ -66,11 +66,11 @@ def _rho(A, Di, iters=15):
 
 
 def _aggregate(A, bs):
-    coo = A.tocoo()
+    # node graph = the bs consecutive CSR rows of a node read as ONE neighbour list (node ids repeat in it, unsorted across
+    # the rows: fep_aggregate_host does not mind) — no COO round trip (1.5 of the hierarchy's 7 s at 1 M DOFs)
     n = A.shape[0] // bs
-    G = ssp.csr_matrix((np.ones(coo.nnz, dtype=np.int8), (coo.row // bs, coo.col // bs)), shape=(n, n))
-    ip = np.ascontiguousarray(G.indptr, dtype=np.int32)
-    ix = np.ascontiguousarray(G.indices, dtype=np.int32)
+    ip = np.ascontiguousarray(A.indptr[::bs], dtype=np.int32)
+    ix = np.ascontiguousarray(A.indices // bs, dtype=np.int32)
     agg = np.empty(n, dtype=np.int32)
     na = C.c_int64()
     _lib.check(_lib.lib().fep_aggregate_host(n, _lib.ptr(ip), _lib.ptr(ix), _lib.ptr(agg), C.byref(na)),
@@ -104,6 +104,35 @@ def _stream(torch, device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _masked_operator(K, f):
+    """Q K Q + (I - Q) without explicit zeros — what `(Dq @ K @ Dq + diags(1 - f)).tocsr()` returns, entry for entry, without
+    the two sparse products and their temporaries (2.1 of the hierarchy's 7 s at 1 M DOFs): rows and columns of the few
+    constrained DOFs zeroed in a copy of the values, their diagonal set to one."""
+    K = ssp.csr_matrix(K)
+    if not K.has_canonical_format:
+        K = K.copy()
+        K.sum_duplicates()
+    ip, ix = K.indptr, K.indices
+    data = K.data.copy()
+    fixed_mask = np.asarray(f) == 0.0
+    data[fixed_mask[ix]] = 0.0                           # columns
+    missing = []
+    for i in np.flatnonzero(fixed_mask):                 # rows, and the diagonal
+        lo, hi = ip[i], ip[i + 1]
+        data[lo:hi] = 0.0
+        t = lo + np.searchsorted(ix[lo:hi], i)
+        if t < hi and ix[t] == i:
+            data[t] = 1.0
+        else:
+            missing.append(i)
+    A = ssp.csr_matrix((data, ix.copy(), ip.copy()), shape=K.shape)
+    A.eliminate_zeros()                                  # (compacts its own index arrays in place)
+    if missing:                                          # a pattern without that diagonal entry
+        m = np.asarray(missing)
+        A = (A + ssp.csr_matrix((np.ones(m.size), (m, m)), shape=A.shape)).tocsr()
+    return A
+
+
 def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8):
     """Smoothed-aggregation hierarchy of Q K Q + (I - Q) (host, SciPy).  Returns one dict per transfer k -> k+1:
     'P' (n_k x n_{k+1}), 'R' = P^T, 'A' = operator of level k+1 (its dense INVERSE in CSR form when 'last'),
@@ -111,7 +140,7 @@ def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8
     (DOFs, nnz) of the level-(k+1) operator — exactly what fep_solver_amg_push_level takes."""
     f = np.asarray(free_dof, dtype=bool).ravel().astype(np.float64)
     Dq = ssp.diags(f)
-    A = (Dq @ K @ Dq + ssp.diags(1.0 - f)).tocsr()
+    A = _masked_operator(K, f)
     xy = np.asarray(coordinates, dtype=np.float64)
     bs, out = 2, []
     Di = _block_diag_inverse(A, bs)

@@ -211,8 +211,9 @@ int fep_transform_host(fep_ctx* ctx, const double* q_int_h, double* q_node_h);
  *   fep_solver_sizes    {n_n, n_dof, nnz, n_free}
  *   fep_solver_spmv_dev y = K x (masked != 0: y = Q K x, x must then be 0 on the constrained DOFs); x != y
  *   fep_solver_pcg_dev  x = 0 on entry is implied; iterates until |r| <= rtol |b[Q]| (recursive residual), at most
- *                       max_iter iterations; the host looks at the device-side state every check_every iterations
- *                       (<= 0: 50) and the iterate is frozen on the device at the iteration that met the test.
+ *                       max_iter iterations; the host looks at the device-side state after at most check_every
+ *                       iterations (<= 0: 50; sooner when the residual history says the test is about to be met) and the
+ *                       iterate is frozen on the device at the iteration that met the test.
  *                       *state_out: 0 = max_iter reached, 1 = converged, 2 = breakdown (K[Q][:,Q] not positive
  *                       definite or non-finite values); x is 0 on constrained DOFs.  Synchronises `stream`. */
 typedef struct fep_solver fep_solver;
@@ -248,7 +249,8 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
  *                               is recomputed by one workgroup) or a product with more than 2^31 terms — the hierarchy is
  *                               left as pushed; an allocation failure drops it.
  *   fep_solver_amg_refresh_dev  the re-projection alone, stream-ordered (FEP_ESTATE unless enabled)
- *   fep_aggregate_host          greedy aggregation of a node graph in CSR: agg_out[i] in [0, *n_agg_out) */
+ *   fep_aggregate_host          greedy aggregation of a node graph in CSR (a neighbour list may repeat ids, in any order):
+ *                               agg_out[i] in [0, *n_agg_out) */
 int fep_solver_amg_clear(fep_solver* solver);
 int fep_solver_amg_enable_refresh(fep_solver* solver);
 int fep_solver_amg_refresh_dev(fep_solver* solver, void* stream, const double* k_data_d);
