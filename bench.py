@@ -141,6 +141,9 @@ def parse_args():
     ap.add_argument('--state', choices=('bands', 'newton', 'random'), default='bands',
                     help="branch mix of the synthetic state: 'bands' ~18 %% smooth / 57 %% apex (default), 'newton' ~29 %% "
                          "smooth / no apex, like the Newton iterates of configs[3]")
+    ap.add_argument('--preheat-ms', type=float, default=250.0,
+                    help='untimed passes of the same step for this long before the W warm-up steps of every timed run (the '
+                         'clocks ramp with load: a 2 ms timed region straight after set-up measures 4-5 %% slower); 0 = off')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-cells', type=int, default=None,
                     help='cells per side of the CPU-baseline square (default: --cells for P1, min(--cells, 354) otherwise: a bounded sample)')
@@ -246,6 +249,12 @@ def run(args):
                     shard.sh.exchange_force_(shard.Fb[i])
                     ev_done[i].record(comm)
 
+        if args.preheat_ms > 0:                         # clock ramp: not part of W, not timed (reported as `preheat_ms`)
+            t_h = time.perf_counter()
+            while time.perf_counter() - t_h < args.preheat_ms * 1e-3:
+                for _ in range(50):
+                    step()
+                torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         barrier()
@@ -421,7 +430,7 @@ def run(args):
         line = {
             'metric': 'element*quadpt updates/sec (return-map + K_tan assemble)',
             'value': n_total * args.steps / dt, 'unit': 'updates/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'preheat_ms': args.preheat_ms,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wl + ', Drucker-Prager, strain->return map->K_tan CSR values->F per step',

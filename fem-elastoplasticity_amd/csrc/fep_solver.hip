@@ -440,17 +440,62 @@ compose_terms_kernel(int64_t n, const int32_t* __restrict__ xa, const int32_t* _
     const int32_t x = xa[t], y = ya[t];
     terms[t] = first ? Term{cv[x], y, 0} : Term{cv[y], x, 0};
 }
+// set-up, the terms built on the device (default; FEP_AMG_PLAN=host keeps fep_host.h's product_plan and the upload of its
+// index pairs): one thread per row i of X walks C(i, :) = sum_x X(i, j) Y(j, :) in ascending order of the X entry — the order
+// of product_plan, so both builders leave identical term lists — and finds every term's output entry by bisection in row i
+// of the (column-sorted) pattern of C.  !FILL: terms per output entry into cnt; FILL: the terms themselves at tptr[c] + cnt[c]++
+// (cnt zeroed before either pass; a row owns its output entries, so the counters need no atomics).  X_CONST: the constant
+// factor is X (R in R * T) and the term carries X's value and Y's entry index, else Y's value and X's entry index.
+// dense_cols > 0: C is dense with that many columns.  *bad != 0: a structural term has no entry in the pattern.
+template <bool FILL, bool X_CONST>
+__global__ void __launch_bounds__(TPB)
+plan_rows_kernel(int64_t n_rows, int64_t n_mid, const int32_t* __restrict__ Xp, const int32_t* __restrict__ Xi,
+                 const int32_t* __restrict__ Yp, const int32_t* __restrict__ Yi, const int32_t* __restrict__ Cp,
+                 const int32_t* __restrict__ Ci, int64_t dense_cols, int32_t* __restrict__ cnt,
+                 const int32_t* __restrict__ tptr, const double* __restrict__ cv, Term* __restrict__ terms, int* bad) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_rows) return;
+    const int64_t c0 = dense_cols ? i * dense_cols : (int64_t)Cp[i];
+    const int64_t c1 = dense_cols ? c0 + dense_cols : (int64_t)Cp[i + 1];
+    for (int32_t x = Xp[i], xe = Xp[i + 1]; x < xe; ++x) {
+        const int32_t j = Xi[x];
+        if (j < 0 || j >= n_mid) { *bad = 2; return; }
+        for (int32_t y = Yp[j], ye = Yp[j + 1]; y < ye; ++y) {
+            const int32_t J = Yi[y];
+            int64_t c = -1;
+            if (dense_cols) {
+                if (J >= 0 && J < dense_cols) c = c0 + J;
+            } else {
+                int64_t lo = c0, hi = c1;                      // first entry of the row with column >= J
+                while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (Ci[m] < J) lo = m + 1; else hi = m; }
+                if (lo < c1 && Ci[lo] == J) c = lo;
+            }
+            if (c < 0) { *bad = 1; return; }
+            if (!FILL) { ++cnt[c]; continue; }
+            const int32_t t = tptr[c] + cnt[c]++;
+            terms[t] = X_CONST ? Term{cv[x], y, 0} : Term{cv[y], x, 0};
+        }
+    }
+}
+// LPE lanes per output entry: lane l takes the entry's terms l, l + LPE, ... (the lanes of an entry read consecutive 16-byte
+// terms: with one lane per entry a wave's loads were 64 lines apart and the kernel ran at 1 TB/s of its 3.4 GB), the partial
+// sums are folded in a fixed butterfly — deterministic, the association differs from the plan's sequential order by rounding.
+template <int LPE>
 __global__ void __launch_bounds__(TPB)
 product_kernel(int64_t n_out, const int32_t* __restrict__ tptr, const Term* __restrict__ terms, const double* __restrict__ V,
                double* __restrict__ out) {
-    const int64_t c = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (c >= n_out) return;
+    const int sub = threadIdx.x & (LPE - 1);
+    const int64_t c = ((int64_t)blockIdx.x * TPB + threadIdx.x) / LPE;
     double a = 0.0;
-    for (int32_t t = tptr[c], e = tptr[c + 1]; t < e; ++t) {
-        const int4 w = *reinterpret_cast<const int4*>(terms + t);
-        a += __hiloint2double(w.y, w.x) * V[w.z];
+    if (c < n_out) {
+        for (int32_t t = tptr[c] + sub, e = tptr[c + 1]; t < e; t += LPE) {
+            const int4 w = *reinterpret_cast<const int4*>(terms + t);
+            a += __hiloint2double(w.y, w.x) * V[w.z];
+        }
     }
-    out[c] = a;
+#pragma unroll
+    for (int o = 1; o < LPE; o <<= 1) a += __shfl_xor(a, o, 64);
+    if (c < n_out && sub == 0) out[c] = a;
 }
 
 // D = inverse of the 3x3 diagonal blocks of a coarse operator, as solver.py builds it (_block_diag_inverse: an empty
@@ -575,7 +620,7 @@ struct fep_solver {
     int n_vec_blocks = 0, n_mv_blocks = 0;
     // multigrid preconditioner: level k (k = 0 is the mesh) -> level k+1
     struct Csr { int64_t n_rows = 0, nnz = 0; int32_t *indptr = nullptr, *indices = nullptr; double* vals = nullptr; };
-    struct Plan { int64_t n_out = 0; int32_t* tptr = nullptr; void* terms = nullptr; };      // terms: (coefficient, value index) x 16 bytes
+    struct Plan { int64_t n_out = 0, n_terms = 0; int32_t* tptr = nullptr; void* terms = nullptr; };      // terms: (coefficient, value index) x 16 bytes
     struct Level {
         int64_t n_fine = 0, n_coarse = 0;
         Csr P, R, A, D;                       // A, D: operator of level k+1 (A = its inverse when last) and its block-Jacobi inverse
@@ -594,11 +639,12 @@ struct fep_solver {
     bool refresh = false;                     // every multigrid solve re-projects the coarse operators from its tangent
     std::vector<Level> levels;
     double *t0 = nullptr, *q = nullptr;       // level-0 residual of the V-cycle, q = K p
-    // single-precision copy of the solve's K for the V-cycle's level-0 passes: FEP_AMG_FP32=1.  Measured at 1 M DOFs, BASELINE
-    // configs[3] end to end: 10.76 s with it, 10.86 s without, the same iteration counts — the passes wait for the gathered
-    // x, not for K's bytes.  Off.
+    // single-precision copy of the solve's K for the V-cycle's four level-0 passes (the preconditioner need not see more than
+    // seven digits of the matrix; CG's own product stays in double precision).  Measured at 1 M DOFs on the LOAD STEPS of BASELINE
+    // configs[3], same session, twice each: 5.93 / 5.95 s with it, 6.20 / 6.43 s without, iteration counts 10 873 / 10 910 (the
+    // first comparison of the round looked at the whole wall, set-up jitter included, and saw 1 %).  On; FEP_AMG_FP32=0 turns it off.
     float* k32 = nullptr;
-    bool fp32 = false;
+    bool fp32 = true;
     // smoother of the V-cycle: degree-2 Chebyshev (default) or two damped block-Jacobi sweeps (FEP_AMG_SMOOTHER=jacobi)
     bool cheb = true;
     double cheb_alpha = 20.0, cheb_safety = 1.2;          // K_elast at 1 M DOFs: alpha 5 / 10 / 20 / 30 -> 77 / 70 / 67 / 66 iterations (Jacobi: 90)
@@ -746,6 +792,8 @@ namespace {
 // iterations already enqueued still run their passes: with a fixed batch of 10 a two-digit multigrid solve of ~80 iterations
 // threw 4.5 of them away on average.  Undershooting costs one more 48-byte read-back, overshooting whole iterations, hence 3/4.
 inline int next_batch(int check_every, double rr_prev, int n_prev, double rr, double target) {
+    static const bool fixed = std::getenv("FEP_PCG_FIXED_BATCH") != nullptr;      // A/B switch: always check_every
+    if (fixed) return check_every;
     if (!(rr_prev > 0.0) || !(rr > 0.0) || n_prev <= 0 || !(rr < rr_prev) || !(target > 0.0)) return check_every;
     if (rr <= target) return 1;
     const double per_it = std::log(rr / rr_prev) / n_prev;             // < 0
@@ -906,62 +954,81 @@ static int push_level_impl(fep_solver* s, int64_t n_fine, int64_t n_coarse,
 // (tools/deflation_study.py; operators one Newton iterate old are worse than those of the elastic matrix).
 // Constrained DOFs need no masking: their rows of P (columns of R) are zero.
 // ---------------------------------------------------------------------------------------
+namespace {
+
+// RAII for the set-up's temporary device arrays
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)) == hipSuccess ? FEP_OK : ((void)hipGetLastError(), FEP_ENOMEM); }
+    int upload(const std::vector<int32_t>& v) {
+        FEP_TRY(alloc(v.size() * sizeof(int32_t)));
+        if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return FEP_EHIP; }
+        return FEP_OK;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+// The terms of C = X * Y on the device (plan_rows_kernel); every pattern is in device memory.  cv_d: values of the constant
+// factor (x_const: X).  Leaves out.tptr / out.terms / out.n_out; *n_terms for the log.
+int device_plan(int64_t n_rows, int64_t n_mid, const int32_t* Xp, const int32_t* Xi, const int32_t* Yp, const int32_t* Yi,
+                const int32_t* Cp, const int32_t* Ci, int64_t dense_cols, int64_t n_out, const double* cv_d, bool x_const,
+                fep_solver::Plan& out, size_t* n_terms) {
+    if (n_out >= INT32_MAX) return FEP_ERANGE;
+    DevTmp cnt, bad;
+    FEP_TRY(cnt.alloc((size_t)n_out * sizeof(int32_t)));
+    FEP_TRY(bad.alloc(sizeof(int)));
+    HIP_TRY(hipMemset(cnt.p, 0, std::max<size_t>((size_t)n_out * sizeof(int32_t), 16)));
+    HIP_TRY(hipMemset(bad.p, 0, sizeof(int)));
+    const dim3 grid((unsigned)((n_rows + TPB - 1) / TPB)), tb(TPB);
+    if (n_rows > 0)
+        hipLaunchKernelGGL((plan_rows_kernel<false, false>), grid, tb, 0, 0, n_rows, n_mid, Xp, Xi, Yp, Yi, Cp, Ci, dense_cols,
+                           cnt.as<int32_t>(), (const int32_t*)nullptr, (const double*)nullptr, (Term*)nullptr, bad.as<int>());
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h((size_t)n_out + 1, 0);
+    int hb = 0;
+    if (n_out > 0) HIP_TRY(hipMemcpy(h.data() + 1, cnt.p, (size_t)n_out * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&hb, bad.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (hb) return hb == 1 ? FEP_EINVAL : FEP_ERANGE;
+    int64_t tot = 0;
+    for (int64_t c = 1; c <= n_out; ++c) {
+        tot += h[(size_t)c];
+        if (tot >= INT32_MAX) return FEP_ERANGE;
+        h[(size_t)c] = (int32_t)tot;
+    }
+    out.n_out = n_out;
+    out.n_terms = tot;
+    if (hipMalloc((void**)&out.tptr, h.size() * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return FEP_ENOMEM; }
+    HIP_TRY(hipMemcpy(out.tptr, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (hipMalloc(&out.terms, std::max<size_t>((size_t)tot, 1) * sizeof(Term)) != hipSuccess) { (void)hipGetLastError(); return FEP_ENOMEM; }
+    HIP_TRY(hipMemset(cnt.p, 0, std::max<size_t>((size_t)n_out * sizeof(int32_t), 16)));
+    if (n_rows > 0 && tot > 0) {
+        if (x_const)
+            hipLaunchKernelGGL((plan_rows_kernel<true, true>), grid, tb, 0, 0, n_rows, n_mid, Xp, Xi, Yp, Yi, Cp, Ci, dense_cols,
+                               cnt.as<int32_t>(), (const int32_t*)out.tptr, cv_d, (Term*)out.terms, bad.as<int>());
+        else
+            hipLaunchKernelGGL((plan_rows_kernel<true, false>), grid, tb, 0, 0, n_rows, n_mid, Xp, Xi, Yp, Yi, Cp, Ci, dense_cols,
+                               cnt.as<int32_t>(), (const int32_t*)out.tptr, cv_d, (Term*)out.terms, bad.as<int>());
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (n_terms) *n_terms = (size_t)tot;
+    return FEP_OK;
+}
+
+}  // namespace
+
 static int enable_refresh_impl(fep_solver* s) {
     if (s->levels.empty() || !s->levels.back().last) return FEP_ESTATE;
     if (s->refresh) return FEP_OK;
     if (s->levels.back().n_coarse > kDenseMax) return FEP_ERANGE;          // (nothing touched: the hierarchy stays usable)
     FEP_TRY(fep_set_device(s->device));
-    // 1. everything on the host first: patterns of A_k P_k and of R_k (A_k P_k), the terms of both products
-    struct HostLevel { std::vector<int32_t> Ap, Ai, d9, nbp, nbc; fep_host::ProductPlan ap, rt; size_t nT = 0; };
-    std::vector<HostLevel> H(s->levels.size());
-    std::vector<int32_t> Xp = s->ip0, Xi = s->ix0;                       // pattern of the operator of level k
-    for (size_t k = 0; k < s->levels.size(); ++k) {
-        const fep_solver::Level& l = s->levels[k];
-        HostLevel& h = H[k];
-        std::vector<int32_t> Tp, Ti;
-        FEP_TRY(fep_host::product_pattern(l.n_fine, l.n_fine, l.n_coarse, Xp.data(), Xi.data(), l.hPp.data(), l.hPi.data(), Tp, Ti));
-        FEP_TRY(fep_host::product_plan(l.n_fine, l.n_fine, Xp.data(), Xi.data(), l.hPp.data(), l.hPi.data(), Tp.data(), Ti.data(), 0, h.ap));
-        h.nT = Ti.size();
-        if (l.last) {                                                    // the coarsest operator is dense (it is inverted)
-            FEP_TRY(fep_host::product_plan(l.n_coarse, l.n_fine, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), nullptr, nullptr, l.n_coarse, h.rt));
-            h.Ap.resize((size_t)l.n_coarse + 1); h.Ai.resize((size_t)(l.n_coarse * l.n_coarse));
-            for (int64_t i = 0; i <= l.n_coarse; ++i) h.Ap[(size_t)i] = (int32_t)(i * l.n_coarse);
-            for (int64_t i = 0; i < l.n_coarse * l.n_coarse; ++i) h.Ai[(size_t)i] = (int32_t)(i % l.n_coarse);
-        } else {
-            if (l.n_coarse % 3 || l.D.nnz != 3 * l.n_coarse) return FEP_EINVAL;
-            // the operator of level k+1 moves onto the pattern of the product (SciPy's may have dropped entries)
-            FEP_TRY(fep_host::product_pattern(l.n_coarse, l.n_fine, l.n_coarse, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), h.Ap, h.Ai));
-            // padded to whole 3x3 node blocks, the three rows of a node on the same block columns (node3_kernel)
-            {
-                const int64_t nn = l.n_coarse / 3;
-                std::vector<int32_t> Ap2((size_t)l.n_coarse + 1, 0), Ai2, cols;
-                h.nbp.assign((size_t)nn + 1, 0);
-                for (int64_t I = 0; I < nn; ++I) {
-                    cols.clear();
-                    for (int32_t t = h.Ap[(size_t)(3 * I)]; t < h.Ap[(size_t)(3 * I + 3)]; ++t) cols.push_back(h.Ai[(size_t)t] / 3);
-                    std::sort(cols.begin(), cols.end());
-                    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-                    h.nbc.insert(h.nbc.end(), cols.begin(), cols.end());
-                    if (h.nbc.size() * 9 >= (size_t)INT32_MAX) return FEP_ERANGE;
-                    h.nbp[(size_t)I + 1] = (int32_t)h.nbc.size();
-                    for (int a = 0; a < 3; ++a) {
-                        for (int32_t J : cols) { Ai2.push_back(3 * J); Ai2.push_back(3 * J + 1); Ai2.push_back(3 * J + 2); }
-                        Ap2[(size_t)(3 * I + a + 1)] = (int32_t)Ai2.size();
-                    }
-                }
-                h.Ap.swap(Ap2); h.Ai.swap(Ai2);
-            }
-            FEP_TRY(fep_host::product_plan(l.n_coarse, l.n_fine, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), h.Ap.data(), h.Ai.data(), 0, h.rt));
-            h.d9.assign((size_t)l.n_coarse * 3, -1);
-            for (int64_t r = 0; r < l.n_coarse; ++r) {
-                const int64_t c0 = r - r % 3;
-                for (int32_t t = h.Ap[(size_t)r]; t < h.Ap[(size_t)r + 1]; ++t)
-                    if (h.Ai[(size_t)t] >= c0 && h.Ai[(size_t)t] < c0 + 3) h.d9[(size_t)(3 * r + (h.Ai[(size_t)t] - c0))] = t;
-            }
-        }
-        Xp = h.Ap; Xi = h.Ai;
-    }
-    // 2. onto the device; a failure here leaves no half-converted hierarchy behind: it is dropped
+    // The host fixes the PATTERNS — A_k P_k, R_k (A_k P_k) padded to whole 3x3 node blocks — level by level; the TERMS of both
+    // products (290 M at 1 M DOFs) are listed on the device from those patterns (device_plan).  FEP_AMG_PLAN=host lists them on
+    // the host as well (fep_host.h product_plan, the form the sanitizer driver replays) and uploads the index pairs: the same
+    // term lists, 0.8 s more of set-up at 1 M DOFs.
+    const char* pm = std::getenv("FEP_AMG_PLAN");
+    const bool host_plan = pm && std::strcmp(pm, "host") == 0;
     int rc = FEP_OK;
     auto up = [&](int32_t** dst, const std::vector<int32_t>& v) {
         if (rc != FEP_OK) return;
@@ -969,9 +1036,10 @@ static int enable_refresh_impl(fep_solver* s) {
         if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipGetLastError(); rc = e == hipErrorOutOfMemory ? FEP_ENOMEM : FEP_EHIP; }
     };
-    // the constant factor's value goes into the term (composed on the device from the index pairs)
+    // host plans: the constant factor's value goes into the term (composed on the device from the index pairs)
     auto up_plan = [&](fep_solver::Plan& d, const fep_host::ProductPlan& h, const double* cv_d, bool first) {
         d.n_out = (int64_t)h.tptr.size() - 1;
+        d.n_terms = (int64_t)h.xa.size();
         up(&d.tptr, h.tptr);
         int32_t *xa = nullptr, *ya = nullptr;
         up(&xa, h.xa); up(&ya, h.ya);
@@ -987,23 +1055,91 @@ static int enable_refresh_impl(fep_solver* s) {
     auto dalloc = [&](double** dst, size_t n) {
         if (rc == FEP_OK && hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
     };
-    for (size_t k = 0; k < s->levels.size(); ++k) {
+    std::vector<size_t> n_ap(s->levels.size(), 0), n_rt(s->levels.size(), 0);
+    std::vector<int32_t> Xp = s->ip0, Xi = s->ix0;                       // pattern of the operator of level k, host ...
+    DevTmp Xp0_d, Xi0_d;                                                 // ... and device (level 0: uploaded for the set-up only)
+    if (!host_plan) { rc = Xp0_d.upload(Xp); if (rc == FEP_OK) rc = Xi0_d.upload(Xi); }
+    const int32_t *Xp_d = Xp0_d.as<int32_t>(), *Xi_d = Xi0_d.as<int32_t>();
+    for (size_t k = 0; k < s->levels.size() && rc == FEP_OK; ++k) {
         fep_solver::Level& l = s->levels[k];
-        const HostLevel& h = H[k];
+        std::vector<int32_t> Ap, Ai, d9, nbp, nbc, Tp, Ti;
+        fep_host::ProductPlan ap, rt;
+        rc = fep_host::product_pattern(l.n_fine, l.n_fine, l.n_coarse, Xp.data(), Xi.data(), l.hPp.data(), l.hPi.data(), Tp, Ti);
+        if (rc != FEP_OK) break;
+        if (host_plan) rc = fep_host::product_plan(l.n_fine, l.n_fine, Xp.data(), Xi.data(), l.hPp.data(), l.hPi.data(), Tp.data(), Ti.data(), 0, ap);
+        if (rc != FEP_OK) break;
+        if (l.last) {                                                    // the coarsest operator is dense (it is inverted)
+            if (host_plan) rc = fep_host::product_plan(l.n_coarse, l.n_fine, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), nullptr, nullptr, l.n_coarse, rt);
+            if (rc != FEP_OK) break;
+            Ap.resize((size_t)l.n_coarse + 1); Ai.resize((size_t)(l.n_coarse * l.n_coarse));
+            for (int64_t i = 0; i <= l.n_coarse; ++i) Ap[(size_t)i] = (int32_t)(i * l.n_coarse);
+            for (int64_t i = 0; i < l.n_coarse * l.n_coarse; ++i) Ai[(size_t)i] = (int32_t)(i % l.n_coarse);
+        } else {
+            if (l.n_coarse % 3 || l.D.nnz != 3 * l.n_coarse) { rc = FEP_EINVAL; break; }
+            // the operator of level k+1 moves onto the pattern of the product (SciPy's may have dropped entries)
+            rc = fep_host::product_pattern(l.n_coarse, l.n_fine, l.n_coarse, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), Ap, Ai);
+            if (rc != FEP_OK) break;
+            // padded to whole 3x3 node blocks, the three rows of a node on the same block columns (node3_kernel)
+            {
+                const int64_t nn = l.n_coarse / 3;
+                std::vector<int32_t> Ap2((size_t)l.n_coarse + 1, 0), Ai2, cols;
+                nbp.assign((size_t)nn + 1, 0);
+                for (int64_t I = 0; I < nn && rc == FEP_OK; ++I) {
+                    cols.clear();
+                    for (int32_t t = Ap[(size_t)(3 * I)]; t < Ap[(size_t)(3 * I + 3)]; ++t) cols.push_back(Ai[(size_t)t] / 3);
+                    std::sort(cols.begin(), cols.end());
+                    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+                    nbc.insert(nbc.end(), cols.begin(), cols.end());
+                    if (nbc.size() * 9 >= (size_t)INT32_MAX) rc = FEP_ERANGE;
+                    nbp[(size_t)I + 1] = (int32_t)nbc.size();
+                    for (int a = 0; a < 3; ++a) {
+                        for (int32_t J : cols) { Ai2.push_back(3 * J); Ai2.push_back(3 * J + 1); Ai2.push_back(3 * J + 2); }
+                        Ap2[(size_t)(3 * I + a + 1)] = (int32_t)Ai2.size();
+                    }
+                }
+                if (rc != FEP_OK) break;
+                Ap.swap(Ap2); Ai.swap(Ai2);
+            }
+            if (host_plan) rc = fep_host::product_plan(l.n_coarse, l.n_fine, l.hRp.data(), l.hRi.data(), Tp.data(), Ti.data(), Ap.data(), Ai.data(), 0, rt);
+            if (rc != FEP_OK) break;
+            d9.assign((size_t)l.n_coarse * 3, -1);
+            for (int64_t r = 0; r < l.n_coarse; ++r) {
+                const int64_t c0 = r - r % 3;
+                for (int32_t t = Ap[(size_t)r]; t < Ap[(size_t)r + 1]; ++t)
+                    if (Ai[(size_t)t] >= c0 && Ai[(size_t)t] < c0 + 3) d9[(size_t)(3 * r + (Ai[(size_t)t] - c0))] = t;
+            }
+        }
+        // onto the device
         free_csr(l.A);
-        l.A.n_rows = l.n_coarse; l.A.nnz = (int64_t)h.Ai.size();
-        up(&l.A.indptr, h.Ap); up(&l.A.indices, h.Ai);
-        dalloc(&l.A.vals, h.Ai.size()); dalloc(&l.T, h.nT);
-        up_plan(l.ap, h.ap, l.P.vals, false); up_plan(l.rt, h.rt, l.R.vals, true);
-        if (!l.last) { up(&l.d9, h.d9); up(&l.nbp, h.nbp); up(&l.nbc, h.nbc); }
+        l.A.n_rows = l.n_coarse; l.A.nnz = (int64_t)Ai.size();
+        up(&l.A.indptr, Ap); up(&l.A.indices, Ai);
+        dalloc(&l.A.vals, Ai.size()); dalloc(&l.T, Ti.size());
+        if (host_plan) {
+            up_plan(l.ap, ap, l.P.vals, false); up_plan(l.rt, rt, l.R.vals, true);
+            n_ap[k] = ap.xa.size(); n_rt[k] = rt.xa.size();
+        } else if (rc == FEP_OK) {
+            DevTmp Tp_d, Ti_d;
+            rc = Tp_d.upload(Tp);
+            if (rc == FEP_OK) rc = Ti_d.upload(Ti);
+            if (rc == FEP_OK)                                            // T = A_k P_k: the constant factor is the second one
+                rc = device_plan(l.n_fine, l.n_fine, Xp_d, Xi_d, l.P.indptr, l.P.indices, Tp_d.as<int32_t>(), Ti_d.as<int32_t>(), 0,
+                                 (int64_t)Ti.size(), l.P.vals, false, l.ap, &n_ap[k]);
+            if (rc == FEP_OK)                                            // A_{k+1} = R_k T: the first one
+                rc = device_plan(l.n_coarse, l.n_fine, l.R.indptr, l.R.indices, Tp_d.as<int32_t>(), Ti_d.as<int32_t>(), l.A.indptr, l.A.indices,
+                                 l.last ? l.n_coarse : 0, (int64_t)Ai.size(), l.R.vals, true, l.rt, &n_rt[k]);
+        }
+        if (!l.last) { up(&l.d9, d9); up(&l.nbp, nbp); up(&l.nbc, nbc); }
+        Xp.swap(Ap); Xi.swap(Ai);
+        Xp_d = l.A.indptr; Xi_d = l.A.indices;
     }
+    // a failure leaves no half-converted hierarchy behind: it is dropped
     if (rc != FEP_OK) { free_levels(s); return rc; }
     if (std::getenv("FEP_VERBOSE")) {
-        std::fprintf(stderr, "[fep] multigrid refresh plans:");
+        std::fprintf(stderr, "[fep] multigrid refresh plans (%s):", host_plan ? "host" : "device");
         for (size_t k = 0; k < s->levels.size(); ++k)
             std::fprintf(stderr, " %lld -> %lld DOFs (A P: %lld entries, %zu terms; R (A P): %lld, %zu)", (long long)s->levels[k].n_fine,
-                         (long long)s->levels[k].n_coarse, (long long)s->levels[k].ap.n_out, H[k].ap.xa.size(),
-                         (long long)s->levels[k].rt.n_out, H[k].rt.xa.size());
+                         (long long)s->levels[k].n_coarse, (long long)s->levels[k].ap.n_out, n_ap[k],
+                         (long long)s->levels[k].rt.n_out, n_rt[k]);
         std::fprintf(stderr, "\n");
     }
     s->refresh = true;
@@ -1021,6 +1157,16 @@ extern "C" int fep_solver_amg_enable_refresh(fep_solver* s) {
     }
 }
 
+// numeric phase of one product: lanes per output entry by the plan's mean term count (A P: ~7 terms, R (A P): ~19)
+static void product_apply(hipStream_t st, const fep_solver::Plan& p, const double* V, double* out) {
+    if (p.n_out <= 0) return;
+    const double mean = (double)p.n_terms / (double)p.n_out;
+    auto grid = [&](int lpe) { return dim3((unsigned)((p.n_out * lpe + TPB - 1) / TPB)); };
+    if (mean >= 12.0) hipLaunchKernelGGL(product_kernel<8>, grid(8), dim3(TPB), 0, st, p.n_out, p.tptr, (const Term*)p.terms, V, out);
+    else if (mean >= 3.0) hipLaunchKernelGGL(product_kernel<4>, grid(4), dim3(TPB), 0, st, p.n_out, p.tptr, (const Term*)p.terms, V, out);
+    else hipLaunchKernelGGL(product_kernel<1>, grid(1), dim3(TPB), 0, st, p.n_out, p.tptr, (const Term*)p.terms, V, out);
+}
+
 extern "C" int fep_solver_amg_refresh_dev(fep_solver* s, void* stream, const double* k_data_d) {
     if (!s || !k_data_d) return FEP_EINVAL;
     if (!s->refresh) return FEP_ESTATE;
@@ -1028,10 +1174,8 @@ extern "C" int fep_solver_amg_refresh_dev(fep_solver* s, void* stream, const dou
     hipStream_t st = (hipStream_t)stream;
     const double* A = k_data_d;
     for (fep_solver::Level& l : s->levels) {
-        hipLaunchKernelGGL(product_kernel, dim3((unsigned)((l.ap.n_out + TPB - 1) / TPB)), dim3(TPB), 0, st, l.ap.n_out,
-                           l.ap.tptr, (const Term*)l.ap.terms, A, l.T);
-        hipLaunchKernelGGL(product_kernel, dim3((unsigned)((l.rt.n_out + TPB - 1) / TPB)), dim3(TPB), 0, st, l.rt.n_out,
-                           l.rt.tptr, (const Term*)l.rt.terms, (const double*)l.T, l.A.vals);
+        product_apply(st, l.ap, A, l.T);
+        product_apply(st, l.rt, (const double*)l.T, l.A.vals);
         if (l.last)
             hipLaunchKernelGGL(dense_inverse_kernel, dim3(1), dim3(1024), 0, st, (int)l.n_coarse, l.A.vals);
         else

@@ -138,7 +138,7 @@ class _DeviceOps:
     def setup_amg(self, K, coordinates):
         # built once from K_elast; rebuilding it from the current tangent when the plastic zone grows was measured
         # (1 M elements, 10 load steps: 6 rebuilds) and did not lower the iteration counts
-        self.solver.setup_amg(self.host(K), coordinates)
+        self.solver.setup_amg(self.host(K), coordinates, k_dev=K)
 
     def solve(self, K, rhs, criterion=None):
         # inexact Newton: while the iterate is far from converged the correction need not be solved to 11 digits.

@@ -133,7 +133,7 @@ def _masked_operator(K, f):
     return A
 
 
-def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8):
+def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8, rho0=None):
     """Smoothed-aggregation hierarchy of Q K Q + (I - Q) (host, SciPy).  Returns one dict per transfer k -> k+1:
     'P' (n_k x n_{k+1}), 'R' = P^T, 'A' = operator of level k+1 (its dense INVERSE in CSR form when 'last'),
     'D' = inverse of A's 3x3 block diagonal (None when 'last'), 'omega' = Jacobi damping on level k, 'size' =
@@ -144,7 +144,7 @@ def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8
     xy = np.asarray(coordinates, dtype=np.float64)
     bs, out = 2, []
     Di = _block_diag_inverse(A, bs)
-    rho = _rho(A, Di)
+    rho = rho0(A, Di) if callable(rho0) else _rho(A, Di)    # (setup_amg runs the mesh level's power iteration on the device)
     for level in range(max_levels):
         agg, na = _aggregate(A, bs)
         Pt, cxy = _tentative(agg, na, xy, bs)
@@ -223,11 +223,39 @@ class KrylovSolver:
             raise ValueError(f'expected {n} contiguous float64 values')
         return v
 
-    def setup_amg(self, K_ref, coordinates, coarse_nodes=400, max_levels=8, refresh=None):
+    def _rho_dev(self, k_dev):
+        """`_rho` for the mesh level with the operator passes on the device: A x = Q K Q x + (I - Q) x through spmv, the block
+        diagonal's inverse as a batched 2x2 product; same start vector, same 15 steps (0.3 of the hierarchy's 1.6 s at 1 M DOFs)."""
+        torch = self._torch
+        kd = self._vec(k_dev, self.nnz)
+        f = torch.from_numpy(self.free_dof.astype(np.float64)).to(self._dev)
+
+        def rho(A, Di, iters=15):
+            D = torch.from_numpy(np.ascontiguousarray(Di.data.reshape(-1, 2, 2))).to(self._dev)
+            x = torch.from_numpy(np.random.default_rng(1).normal(size=A.shape[0])).to(self._dev)
+            y = torch.empty_like(x)
+            lam = 1.0
+            for _ in range(iters):
+                xq = x * f
+                self.spmv(kd, xq, out=y, masked=True)
+                y += x - xq
+                y = torch.bmm(D, y.view(-1, 2, 1)).reshape(-1)
+                ny = float(torch.linalg.vector_norm(y))
+                if ny == 0.0:
+                    return 1.0
+                lam = ny / float(torch.linalg.vector_norm(x))
+                x = y / ny
+                y = torch.empty_like(x)
+            return float(lam)
+        return rho
+
+    def setup_amg(self, K_ref, coordinates, coarse_nodes=400, max_levels=8, refresh=None, k_dev=None):
         """Builds the multigrid hierarchy from `K_ref` (csr_matrix on the pattern, or its data array; host) and the
         node coordinates (2, n_n), and loads it onto the device.  Returns [(DOFs, nnz)] per level.
         `refresh` (default: on unless FEP_AMG_REFRESH=0): every solve re-projects the coarse operators from its own
-        tangent with the transfers built here (fep_solver_amg_enable_refresh); `self.amg_refresh` tells whether it is on."""
+        tangent with the transfers built here (fep_solver_amg_enable_refresh); `self.amg_refresh` tells whether it is on.
+        `k_dev`: the same values as a device tensor, when the caller has them there (the mesh level's eigenvalue estimate then
+        runs on the device)."""
         if not hasattr(self, '_pattern'):
             raise ValueError('setup_amg needs the solver to have been created from a pattern')
         ip, ix = self._pattern
@@ -238,7 +266,8 @@ class KrylovSolver:
         if refresh:                                      # the coarsest operator is re-inverted by every solve: keep it small
             coarse_nodes = min(coarse_nodes, 64)
         t0 = time.perf_counter()
-        levels = build_amg_hierarchy(K, self.free_dof, coordinates, coarse_nodes, max_levels)
+        levels = build_amg_hierarchy(K, self.free_dof, coordinates, coarse_nodes, max_levels,
+                                     rho0=None if k_dev is None else self._rho_dev(k_dev))
         t1 = time.perf_counter()
         l = _lib.lib()
         _lib.check(l.fep_solver_amg_clear(self._h), 'fep_solver_amg_clear')

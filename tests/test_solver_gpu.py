@@ -148,6 +148,29 @@ def test_multigrid_refresh_reprojects_the_coarse_operators(fep, et, n):
     ctx.close()
 
 
+@pytest.mark.parametrize('et,n', [('P1', 64), ('Q2', 12)])
+def test_refresh_terms_listed_on_the_device_are_the_host_plan(fep, et, n, monkeypatch):
+    """The terms of the numeric Galerkin products are listed on the device (plan_rows_kernel, one thread per row of the first
+    factor) — FEP_AMG_PLAN=host lists them with fep_host.h's product_plan (the builder the sanitizer driver replays against the
+    triple loop) and uploads the index pairs.  Same terms in the same order: the refreshed operators and with them every
+    iterate of the solve are bit-identical."""
+    mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
+    K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
+    b = rng.normal(size=ctx.n_dof)
+    out = {}
+    for mode in ('device', 'host'):
+        monkeypatch.setenv('FEP_AMG_PLAN', mode)
+        sol = fep.KrylovSolver(ctx, qf)
+        sol.setup_amg(K_el, mesh['coordinates'], coarse_nodes=30, refresh=True)
+        assert sol.amg_refresh
+        out[mode] = [(sol.solve_host(K, b, rtol=1e-11), sol.last['iters'], sol.last['relres']) for K in (K_el, r['K'])]
+        assert sol.last['state'] == 1
+        sol.close()
+    for (xd, itd, rd), (xh, ith, rh) in zip(out['device'], out['host']):
+        assert itd == ith and rd == rh and np.array_equal(xd, xh)
+    ctx.close()
+
+
 def test_drivers_with_multigrid_solver(fep):
     from conftest import load_golden
     g = load_golden('dp_p1_level1_trace')
