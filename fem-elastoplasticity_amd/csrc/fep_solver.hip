@@ -329,6 +329,52 @@ csr_kernel(int64_t n_rows, const int32_t* __restrict__ indptr, const int32_t* __
     }
 }
 
+// Transfers in node blocks, single-precision values (Level::Blocks).
+// Prolongation, one lane per fine node:  y(node) = z(node) + sum_blocks B (BF x 3) xc(coarse node)      (y may alias z)
+template <int BF>
+__global__ void __launch_bounds__(TPB)
+prolong_block_kernel(int64_t n_fine_nodes, const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                     const float* __restrict__ val, const double* __restrict__ xc, const double* z, double* y) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_fine_nodes) return;
+    double a[BF];
+#pragma unroll
+    for (int r = 0; r < BF; ++r) a[r] = 0.0;
+    for (int32_t t = ptr[i], e = ptr[i + 1]; t < e; ++t) {
+        const double* xj = xc + 3 * (int64_t)col[t];
+        const double x0 = xj[0], x1 = xj[1], x2 = xj[2];
+        const float* v = val + (int64_t)t * (3 * BF);
+#pragma unroll
+        for (int r = 0; r < BF; ++r) a[r] += (double)v[3 * r] * x0 + (double)v[3 * r + 1] * x1 + (double)v[3 * r + 2] * x2;
+    }
+#pragma unroll
+    for (int r = 0; r < BF; ++r) y[BF * i + r] = z[BF * i + r] + a[r];
+}
+
+// Restriction, 8 lanes per coarse node:  bc(coarse node) = sum_blocks B^T (3 x BF) r(fine node)
+template <int BF>
+__global__ void __launch_bounds__(TPB)
+restrict_block_kernel(int64_t n_coarse_nodes, const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                      const float* __restrict__ val, const double* __restrict__ r, double* __restrict__ bc) {
+    const int sub = threadIdx.x & 7;
+    const int64_t J = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 3;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (J < n_coarse_nodes) {
+        for (int32_t t = ptr[J] + sub, e = ptr[J + 1]; t < e; t += 8) {
+            const double* ri = r + BF * (int64_t)col[t];
+            const float* v = val + (int64_t)t * (3 * BF);
+#pragma unroll
+            for (int q = 0; q < BF; ++q) {
+                const double rv = ri[q];
+                a0 += (double)v[q] * rv; a1 += (double)v[BF + q] * rv; a2 += (double)v[2 * BF + q] * rv;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    if (J < n_coarse_nodes && sub == 0) { bc[3 * J] = a0; bc[3 * J + 1] = a1; bc[3 * J + 2] = a2; }
+}
+
 // standard PCG pieces around the V-cycle
 __global__ void __launch_bounds__(TPB)
 mg_init_kernel(int64_t n_n, const double2* __restrict__ b, const uint8_t* __restrict__ free_dof, double2* __restrict__ x,
@@ -634,6 +680,14 @@ struct fep_solver {
         int32_t* d9 = nullptr;
         int32_t *nbp = nullptr, *nbc = nullptr;                             // node blocks of the padded A (node3_kernel)
         double* xcur = nullptr;                                             // which of x / t / r holds the level's iterate
+        // The transfers once more for the V-cycle, in node blocks and single precision (the refresh plans keep the double-precision
+        // CSR): a fine node (BF = 2 DOFs on the mesh level, 3 below) against a coarse node (3 DOFs) is one BF x 3 block — one
+        // column id per block instead of one per entry, 4-byte values: P_0 at 1 M DOFs 36 instead of 92 MB per pass.
+        struct Blocks {
+            int bf = 0; int64_t nf = 0, nc = 0, nblk = 0;
+            int32_t *pptr = nullptr, *pcol = nullptr; float* pval = nullptr;   // per fine node: (coarse node, BF x 3 values, row-major)
+            int32_t *rptr = nullptr, *rcol = nullptr; float* rval = nullptr;   // per coarse node: (fine node, 3 x BF values) = the transposes
+        } tb;
     };
     std::vector<int32_t> ip0, ix0;            // scalar pattern of K on the host (refresh plans)
     bool refresh = false;                     // every multigrid solve re-projects the coarse operators from its tangent
@@ -645,6 +699,7 @@ struct fep_solver {
     // first comparison of the round looked at the whole wall, set-up jitter included, and saw 1 %).  On; FEP_AMG_FP32=0 turns it off.
     float* k32 = nullptr;
     bool fp32 = true;
+    bool block_transfers = true;              // Level::Blocks for the V-cycle's transfers (FEP_AMG_BLOCK_TRANSFERS=0: the CSR forms)
     // smoother of the V-cycle: degree-2 Chebyshev (default) or two damped block-Jacobi sweeps (FEP_AMG_SMOOTHER=jacobi)
     bool cheb = true;
     double cheb_alpha = 20.0, cheb_safety = 1.2;          // K_elast at 1 M DOFs: alpha 5 / 10 / 20 / 30 -> 77 / 70 / 67 / 66 iterations (Jacobi: 90)
@@ -661,12 +716,17 @@ static void free_plan(fep_solver::Plan& p) {
     if (p.terms) (void)hipFree(p.terms);
     p = fep_solver::Plan();
 }
+static void free_blocks(fep_solver::Level::Blocks& b) {
+    for (void* v : {(void*)b.pptr, (void*)b.pcol, (void*)b.pval, (void*)b.rptr, (void*)b.rcol, (void*)b.rval}) if (v) (void)hipFree(v);
+    b = fep_solver::Level::Blocks();
+}
 static void free_levels(fep_solver* s) {
     for (auto& l : s->levels) {
         free_csr(l.P); free_csr(l.R); free_csr(l.A); free_csr(l.D);
         for (double* v : {l.x, l.b, l.r, l.t, l.T}) if (v) (void)hipFree(v);
         free_plan(l.ap); free_plan(l.rt);
         for (int32_t* v : {l.d9, l.nbp, l.nbc}) if (v) (void)hipFree(v);
+        free_blocks(l.tb);
     }
     s->levels.clear();
     s->refresh = false;
@@ -736,6 +796,7 @@ static int solver_create_impl(fep_solver** out, int device_id, int64_t n_n, cons
     if (const char* sm = std::getenv("FEP_AMG_SMOOTHER")) s->cheb = std::strcmp(sm, "jacobi") != 0;
     if (const char* al = std::getenv("FEP_AMG_CHEB_ALPHA")) { const double v = std::atof(al); if (v > 1.0) s->cheb_alpha = v; }
     if (const char* f32 = std::getenv("FEP_AMG_FP32")) s->fp32 = std::strcmp(f32, "0") != 0;
+    if (const char* bt = std::getenv("FEP_AMG_BLOCK_TRANSFERS")) s->block_transfers = std::strcmp(bt, "0") != 0;
     if (const char* sf = std::getenv("FEP_AMG_CHEB_SAFETY")) { const double v = std::atof(sf); if (v >= 1.0) s->cheb_safety = v; }
     s->device = device_id; s->n_n = n_n; s->n_dof = n_dof; s->n_blk = n_blk;
     s->ip0.assign(indptr_h, indptr_h + n_dof + 1);
@@ -903,6 +964,63 @@ extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t 
     }
 }
 
+// Level::Blocks from the prolongation in CSR (host): the blocks of a fine node = the coarse nodes any of its BF rows reaches
+// (ascending), entries a row does not hold are zero; the restriction's blocks are the transposes, fine nodes ascending.
+// A level whose sizes are not whole nodes keeps the CSR form (tb.bf stays 0).
+static int build_transfer_blocks(fep_solver::Level& l, int bf, const int32_t* Pp, const int32_t* Pi, const double* Pv) {
+    if (l.n_fine % bf || l.n_coarse % 3) return FEP_OK;
+    const int64_t nf = l.n_fine / bf, nc = l.n_coarse / 3;
+    std::vector<int32_t> pptr((size_t)nf + 1, 0), pcol, cols;
+    std::vector<float> pval;
+    for (int64_t i = 0; i < nf; ++i) {
+        cols.clear();
+        for (int32_t t = Pp[bf * i]; t < Pp[bf * i + bf]; ++t) {
+            if (Pi[t] < 0 || Pi[t] >= l.n_coarse) return FEP_ERANGE;
+            cols.push_back(Pi[t] / 3);
+        }
+        std::sort(cols.begin(), cols.end());
+        cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+        const size_t b0 = pcol.size();
+        pcol.insert(pcol.end(), cols.begin(), cols.end());
+        pval.resize(pcol.size() * (size_t)(3 * bf), 0.0f);
+        for (int r = 0; r < bf; ++r)
+            for (int32_t t = Pp[bf * i + r]; t < Pp[bf * i + r + 1]; ++t) {
+                const size_t b = b0 + (size_t)(std::lower_bound(cols.begin(), cols.end(), Pi[t] / 3) - cols.begin());
+                pval[b * (size_t)(3 * bf) + (size_t)(3 * r + Pi[t] % 3)] = (float)Pv[t];
+            }
+        if (pcol.size() >= (size_t)INT32_MAX / 9) return FEP_ERANGE;
+        pptr[(size_t)i + 1] = (int32_t)pcol.size();
+    }
+    const size_t nblk = pcol.size();
+    std::vector<int32_t> rptr((size_t)nc + 1, 0), rcol(nblk), fill;
+    std::vector<float> rval(nblk * (size_t)(3 * bf));
+    for (size_t b = 0; b < nblk; ++b) ++rptr[(size_t)pcol[b] + 1];
+    for (int64_t J = 0; J < nc; ++J) rptr[(size_t)J + 1] += rptr[(size_t)J];
+    fill.assign(rptr.begin(), rptr.end() - 1);
+    for (int64_t i = 0; i < nf; ++i)
+        for (int32_t b = pptr[(size_t)i]; b < pptr[(size_t)i + 1]; ++b) {
+            const size_t q = (size_t)fill[(size_t)pcol[(size_t)b]]++;
+            rcol[q] = (int32_t)i;
+            for (int r = 0; r < bf; ++r)
+                for (int c = 0; c < 3; ++c) rval[q * (size_t)(3 * bf) + (size_t)(c * bf + r)] = pval[(size_t)b * (size_t)(3 * bf) + (size_t)(3 * r + c)];
+        }
+    fep_solver::Level::Blocks& B = l.tb;
+    auto up = [&](void** dst, const void* src, size_t bytes) {
+        if (hipMalloc(dst, std::max<size_t>(bytes, 16)) != hipSuccess) { (void)hipGetLastError(); return FEP_ENOMEM; }
+        if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return FEP_EHIP; }
+        return FEP_OK;
+    };
+    int rc = up((void**)&B.pptr, pptr.data(), pptr.size() * 4);
+    if (rc == FEP_OK) rc = up((void**)&B.pcol, pcol.data(), pcol.size() * 4);
+    if (rc == FEP_OK) rc = up((void**)&B.pval, pval.data(), pval.size() * 4);
+    if (rc == FEP_OK) rc = up((void**)&B.rptr, rptr.data(), rptr.size() * 4);
+    if (rc == FEP_OK) rc = up((void**)&B.rcol, rcol.data(), rcol.size() * 4);
+    if (rc == FEP_OK) rc = up((void**)&B.rval, rval.data(), rval.size() * 4);
+    if (rc != FEP_OK) { free_blocks(B); return rc; }
+    B.bf = bf; B.nf = nf; B.nc = nc; B.nblk = (int64_t)nblk;
+    return FEP_OK;
+}
+
 static int push_level_impl(fep_solver* s, int64_t n_fine, int64_t n_coarse,
                            const int32_t* p_indptr, const int32_t* p_indices, const double* p_vals,
                            const int32_t* r_indptr, const int32_t* r_indices, const double* r_vals,
@@ -927,6 +1045,7 @@ static int push_level_impl(fep_solver* s, int64_t n_fine, int64_t n_coarse,
     }
     if (rc == FEP_OK) rc = upload_csr(l.A, n_coarse, n_coarse, a_indptr, a_indices, a_vals);
     if (rc == FEP_OK && !last) rc = upload_csr(l.D, n_coarse, n_coarse, d_indptr, d_indices, d_vals);
+    if (rc == FEP_OK && s->block_transfers) rc = build_transfer_blocks(l, s->levels.size() == 1 ? 2 : 3, p_indptr, p_indices, p_vals);
     for (double** v : {&l.x, &l.b, &l.r, &l.t})
         if (rc == FEP_OK && hipMalloc((void**)v, (size_t)n_coarse * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();
@@ -940,6 +1059,7 @@ static int push_level_impl(fep_solver* s, int64_t n_fine, int64_t n_coarse,
     if (rc != FEP_OK) {
         fep_solver::Level& b = s->levels.back();
         free_csr(b.P); free_csr(b.R); free_csr(b.A); free_csr(b.D);
+        free_blocks(b.tb);
         for (double* v : {b.x, b.b, b.r, b.t}) if (v) (void)hipFree(v);
         s->levels.pop_back();
     }
@@ -1205,6 +1325,22 @@ inline void csr_apply2(hipStream_t st, const fep_solver::Csr& m, const double* x
     hipLaunchKernelGGL((csr_kernel<true, 8>), dim3(grid), dim3(TPB), 0, st, m.n_rows, m.indptr, m.indices, m.vals, x, z, c0, c1, y, z2, c2);
 }
 
+// restriction b_coarse = R r and prolongation x = x + P x_coarse of one transfer: node blocks when the level has them
+inline void restrict_apply(hipStream_t st, const fep_solver::Level& l, const double* r, double* bc) {
+    const fep_solver::Level::Blocks& B = l.tb;
+    if (!B.bf) { csr_apply(st, l.R, r, nullptr, 0.0, 1.0, bc); return; }
+    const dim3 g((unsigned)((B.nc * 8 + TPB - 1) / TPB)), tb(TPB);
+    if (B.bf == 2) hipLaunchKernelGGL(restrict_block_kernel<2>, g, tb, 0, st, B.nc, B.rptr, B.rcol, B.rval, r, bc);
+    else hipLaunchKernelGGL(restrict_block_kernel<3>, g, tb, 0, st, B.nc, B.rptr, B.rcol, B.rval, r, bc);
+}
+inline void prolong_apply(hipStream_t st, const fep_solver::Level& l, const double* xc, double* x) {
+    const fep_solver::Level::Blocks& B = l.tb;
+    if (!B.bf) { csr_apply(st, l.P, xc, x, 1.0, 1.0, x); return; }
+    const dim3 g((unsigned)((B.nf + TPB - 1) / TPB)), tb(TPB);
+    if (B.bf == 2) hipLaunchKernelGGL(prolong_block_kernel<2>, g, tb, 0, st, B.nf, B.pptr, B.pcol, B.pval, xc, x, x);
+    else hipLaunchKernelGGL(prolong_block_kernel<3>, g, tb, 0, st, B.nf, B.pptr, B.pcol, B.pval, xc, x, x);
+}
+
 // one level-0 pass of the V-cycle (block_residual_kernel) on the solve's K — its single-precision copy when there is one
 template <int SMOOTH>
 inline void block_pass(fep_solver* s, hipStream_t st, const double* K, const double* x, const double* b, double omega, double* out,
@@ -1245,7 +1381,7 @@ double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0)
     hipLaunchKernelGGL(block_scale_kernel, gv, tb, 0, st, s->n_n, s->free_dof, s->minv, (const double2*)b0, w0, (double2*)xa);
     block_pass<1>(s, st, K, xa, b0, w0, xb, 1.0, 0.0, nullptr);
     block_pass<0>(s, st, K, xb, b0, 0.0, s->t0, 1.0, 0.0, nullptr);
-    csr_apply(st, L[0].R, s->t0, nullptr, 0.0, 1.0, L[0].b);
+    restrict_apply(st, L[0], s->t0, L[0].b);
     // coarse levels down: level k+1 lives in L[k].{A, D, x, b, r}; its smoother weight is L[k+1].omega
     for (int k = 0; k + 1 < nl; ++k) {
         fep_solver::Level& c = L[k];
@@ -1254,7 +1390,7 @@ double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0)
         csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);                // r = b - A x
         csr_apply(st, c.D, c.r, c.x, 1.0, w, c.x);                   // x += w D r
         csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
-        csr_apply(st, L[k + 1].R, c.r, nullptr, 0.0, 1.0, L[k + 1].b);
+        restrict_apply(st, L[k + 1], c.r, L[k + 1].b);
     }
     // coarsest: x = A^-1 b (A holds the inverse)
     csr_apply(st, L[nl - 1].A, L[nl - 1].b, nullptr, 0.0, 1.0, L[nl - 1].x);
@@ -1262,13 +1398,13 @@ double* vcycle(fep_solver* s, hipStream_t st, const double* K, const double* b0)
     for (int k = nl - 2; k >= 0; --k) {
         fep_solver::Level& c = L[k];
         const double w = L[k + 1].omega;
-        csr_apply(st, L[k + 1].P, L[k + 1].x, c.x, 1.0, 1.0, c.x);   // x += P x_coarse
+        prolong_apply(st, L[k + 1], L[k + 1].x, c.x);                // x += P x_coarse
         for (int sw = 0; sw < 2; ++sw) {
             csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
             csr_apply(st, c.D, c.r, c.x, 1.0, w, c.x);
         }
     }
-    csr_apply(st, L[0].P, L[0].x, xb, 1.0, 1.0, xb);
+    prolong_apply(st, L[0], L[0].x, xb);
     block_pass<1>(s, st, K, xb, b0, w0, xa, 1.0, 0.0, nullptr);
     block_pass<1>(s, st, K, xa, b0, w0, xb, 1.0, 0.0, nullptr);
     return xb;
@@ -1288,7 +1424,7 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
     hipLaunchKernelGGL(block_scale_kernel, gv, tb, 0, st, s->n_n, s->free_dof, s->minv, (const double2*)b0, c0.c1, (double2*)xa);
     block_pass<2>(s, st, K, xa, b0, c0.w2, xb, c0.a2, 0.0, nullptr);
     block_pass<0>(s, st, K, xb, b0, 0.0, s->t0, 1.0, 0.0, nullptr);
-    csr_apply(st, L[0].R, s->t0, nullptr, 0.0, 1.0, L[0].b);
+    restrict_apply(st, L[0], s->t0, L[0].b);
     // with the refresh the coarse operators sit on whole 3x3 node blocks: node3_kernel does an operator pass and the
     // block-Jacobi step behind it in one launch (7 launches per level and cycle instead of 10)
     const bool n3 = s->refresh;
@@ -1314,14 +1450,14 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
             csr_apply(st, c.A, c.x, c.b, 1.0, -1.0, c.r);
             c.xcur = c.x;
         }
-        csr_apply(st, L[k + 1].R, c.r, nullptr, 0.0, 1.0, L[k + 1].b);
+        restrict_apply(st, L[k + 1], c.r, L[k + 1].b);
     }
     csr_apply(st, L[nl - 1].A, L[nl - 1].b, nullptr, 0.0, 1.0, L[nl - 1].x);
     L[nl - 1].xcur = L[nl - 1].x;
     for (int k = nl - 2; k >= 0; --k) {
         fep_solver::Level& c = L[k];
         const Cheb ch = cheb_coefficients(L[k + 1].omega, s->cheb_alpha, s->cheb_safety);
-        csr_apply(st, L[k + 1].P, L[k + 1].xcur, c.xcur, 1.0, 1.0, c.xcur);   // x0 = x + P x_coarse
+        prolong_apply(st, L[k + 1], L[k + 1].xcur, c.xcur);         // x0 = x + P x_coarse
         if (n3) {
             double* x1 = c.xcur == c.t ? c.x : c.t;
             node3(1, c, c.xcur, ch.c1, 1.0, 0.0, nullptr, x1);       // x1 = x0 + c1 D (b - A x0)
@@ -1334,7 +1470,7 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
             csr_apply2(st, c.D, c.r, c.t, ch.a2, c.x, ch.cp, ch.w2, c.x);   // x2 = a2 x1 + cp x0 + w2 D r1
         }
     }
-    csr_apply(st, L[0].P, L[0].xcur, xb, 1.0, 1.0, xb);              // x0
+    prolong_apply(st, L[0], L[0].xcur, xb);                           // x0
     block_pass<1>(s, st, K, xb, b0, c0.c1, xa, 1.0, 0.0, nullptr);   // x1 = x0 + c1 D^-1 r0
     block_pass<2>(s, st, K, xa, b0, c0.w2, s->t0, c0.a2, c0.cp, xb);  // x2 -> t0
     return s->t0;

@@ -171,6 +171,33 @@ def test_refresh_terms_listed_on_the_device_are_the_host_plan(fep, et, n, monkey
     ctx.close()
 
 
+@pytest.mark.parametrize('et,n', [('P1', 64), ('Q2', 12)])
+def test_block_transfers_are_the_csr_transfers_in_single_precision(fep, et, n, monkeypatch):
+    """The V-cycle applies its transfers in node blocks with single-precision values (prolong_block_kernel /
+    restrict_block_kernel); FEP_AMG_BLOCK_TRANSFERS=0 keeps the double-precision CSR forms.  The same preconditioner up to seven
+    digits of the transfers: the same iteration counts (+-2), the same solution, still symmetric (CG converges monotonically
+    enough to meet 1e-11), run-to-run bit-identical."""
+    mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
+    K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
+    b = rng.normal(size=ctx.n_dof)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('FEP_AMG_BLOCK_TRANSFERS', mode)
+        sol = fep.KrylovSolver(ctx, qf)
+        sol.setup_amg(K_el, mesh['coordinates'], coarse_nodes=30)
+        res = []
+        for K in (K_el, r['K']):
+            x = sol.solve_host(K, b, rtol=1e-11)
+            assert sol.last['state'] == 1 and np.array_equal(x, sol.solve_host(K, b, rtol=1e-11))
+            assert np.linalg.norm((K @ x - b)[qf]) <= 1e-9 * np.linalg.norm(b[qf])
+            res.append((x, sol.last['iters']))
+        out[mode] = res
+        sol.close()
+    for (xb, itb), (xc, itc) in zip(out['1'], out['0']):
+        assert abs(itb - itc) <= 2 and relerr(xb, xc) <= 1e-8
+    ctx.close()
+
+
 def test_drivers_with_multigrid_solver(fep):
     from conftest import load_golden
     g = load_golden('dp_p1_level1_trace')
