@@ -304,6 +304,12 @@ to_float_kernel(int64_t n4, const double4* __restrict__ in, float4* __restrict__
     out[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
 }
 
+__global__ void __launch_bounds__(TPB)
+to_float1_kernel(int64_t n, const double* __restrict__ in, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
 // Coarse levels and transfers: scalar CSR, 8 lanes per row:  y = c0 * z + c1 * A x   (z == nullptr: y = c1 * A x;
 // y may alias z, never x)
 // Z2: y = c0 * z + c2 * z2 + c1 * A x  (y may alias z or z2)
@@ -572,9 +578,11 @@ block3_inverse_kernel(int64_t n_nodes, const int32_t* __restrict__ d9, const dou
 // spot — the smoothing step that took an operator pass and a D pass is one kernel:
 //   MODE 0: out = b - A x      MODE 1: out = x + om D (b - A x)      MODE 2: out = ca x + cp xp + om D (b - A x)
 // out never aliases x (neighbours read it); it may alias xp.
-template <int MODE>
+// AV = float: the operator's single-precision copy (to_float_kernel after every refresh; the smoother need not see more than
+// seven digits of it — level 1 at 1 M mesh DOFs: 30 instead of 60 MB per pass, four passes per cycle).
+template <int MODE, typename AV>
 __global__ void __launch_bounds__(TPB)
-node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __restrict__ nbc, const double* __restrict__ A,
+node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __restrict__ nbc, const AV* __restrict__ A,
              const double* __restrict__ D, const double* __restrict__ x, const double* __restrict__ b, double om, double ca,
              double cp, const double* xp, double* out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -587,15 +595,15 @@ node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __
         acc[ps][0] = acc[ps][1] = acc[ps][2] = 0.0;
         if (n < n_nodes) {
             const int b0 = nbp[n], deg = nbp[n + 1] - b0;
-            const double* r0 = A + 9 * (int64_t)b0;
-            const double* r1 = r0 + 3 * deg;
-            const double* r2 = r1 + 3 * deg;
+            const AV* r0 = A + 9 * (int64_t)b0;
+            const AV* r1 = r0 + 3 * deg;
+            const AV* r2 = r1 + 3 * deg;
             for (int t = sub; t < deg; t += 8) {
                 const double* xv = x + 3 * (int64_t)nbc[b0 + t];
                 const double x0 = xv[0], x1 = xv[1], x2 = xv[2];
-                acc[ps][0] += r0[3 * t] * x0 + r0[3 * t + 1] * x1 + r0[3 * t + 2] * x2;
-                acc[ps][1] += r1[3 * t] * x0 + r1[3 * t + 1] * x1 + r1[3 * t + 2] * x2;
-                acc[ps][2] += r2[3 * t] * x0 + r2[3 * t + 1] * x1 + r2[3 * t + 2] * x2;
+                acc[ps][0] += (double)r0[3 * t] * x0 + (double)r0[3 * t + 1] * x1 + (double)r0[3 * t + 2] * x2;
+                acc[ps][1] += (double)r1[3 * t] * x0 + (double)r1[3 * t + 1] * x1 + (double)r1[3 * t + 2] * x2;
+                acc[ps][2] += (double)r2[3 * t] * x0 + (double)r2[3 * t + 1] * x1 + (double)r2[3 * t + 2] * x2;
             }
         }
     }
@@ -677,6 +685,7 @@ struct fep_solver {
         // refresh: T = A_k P (values only), A_{k+1} = R T, positions of the 3x3 diagonal blocks in A_{k+1}
         Plan ap, rt;
         double* T = nullptr;
+        float* A32 = nullptr;                                               // single-precision copy of A's values for node3_kernel
         int32_t* d9 = nullptr;
         int32_t *nbp = nullptr, *nbc = nullptr;                             // node blocks of the padded A (node3_kernel)
         double* xcur = nullptr;                                             // which of x / t / r holds the level's iterate
@@ -724,6 +733,7 @@ static void free_levels(fep_solver* s) {
     for (auto& l : s->levels) {
         free_csr(l.P); free_csr(l.R); free_csr(l.A); free_csr(l.D);
         for (double* v : {l.x, l.b, l.r, l.t, l.T}) if (v) (void)hipFree(v);
+        if (l.A32) (void)hipFree(l.A32);
         free_plan(l.ap); free_plan(l.rt);
         for (int32_t* v : {l.d9, l.nbp, l.nbc}) if (v) (void)hipFree(v);
         free_blocks(l.tb);
@@ -1234,6 +1244,7 @@ static int enable_refresh_impl(fep_solver* s) {
         l.A.n_rows = l.n_coarse; l.A.nnz = (int64_t)Ai.size();
         up(&l.A.indptr, Ap); up(&l.A.indices, Ai);
         dalloc(&l.A.vals, Ai.size()); dalloc(&l.T, Ti.size());
+        if (rc == FEP_OK && s->fp32 && !l.last && hipMalloc((void**)&l.A32, std::max<size_t>(Ai.size(), 4) * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); rc = FEP_ENOMEM; }
         if (host_plan) {
             up_plan(l.ap, ap, l.P.vals, false); up_plan(l.rt, rt, l.R.vals, true);
             n_ap[k] = ap.xa.size(); n_rt[k] = rt.xa.size();
@@ -1298,9 +1309,13 @@ extern "C" int fep_solver_amg_refresh_dev(fep_solver* s, void* stream, const dou
         product_apply(st, l.rt, (const double*)l.T, l.A.vals);
         if (l.last)
             hipLaunchKernelGGL(dense_inverse_kernel, dim3(1), dim3(1024), 0, st, (int)l.n_coarse, l.A.vals);
-        else
+        else {
             hipLaunchKernelGGL(block3_inverse_kernel, dim3((unsigned)((l.n_coarse / 3 + TPB - 1) / TPB)), dim3(TPB), 0, st,
                                l.n_coarse / 3, l.d9, l.A.vals, l.D.vals);
+            if (l.A32)
+                hipLaunchKernelGGL(to_float1_kernel, dim3((unsigned)((l.A.nnz + TPB - 1) / TPB)), dim3(TPB), 0, st, l.A.nnz,
+                                   (const double*)l.A.vals, l.A32);
+        }
         A = l.A.vals;
     }
     HIP_TRY(hipGetLastError());
@@ -1432,9 +1447,17 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
                      double* out) {
         const int64_t nn = c.n_coarse / 3;
         const dim3 g((unsigned)((nn + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK));
-        if (mode == 0) hipLaunchKernelGGL(node3_kernel<0>, g, tb, 0, st, nn, c.nbp, c.nbc, c.A.vals, c.D.vals, x, c.b, om, ca, cp, xp, out);
-        else if (mode == 1) hipLaunchKernelGGL(node3_kernel<1>, g, tb, 0, st, nn, c.nbp, c.nbc, c.A.vals, c.D.vals, x, c.b, om, ca, cp, xp, out);
-        else hipLaunchKernelGGL(node3_kernel<2>, g, tb, 0, st, nn, c.nbp, c.nbc, c.A.vals, c.D.vals, x, c.b, om, ca, cp, xp, out);
+        if (c.A32) {
+            const float* A = c.A32;
+            if (mode == 0) hipLaunchKernelGGL((node3_kernel<0, float>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+            else if (mode == 1) hipLaunchKernelGGL((node3_kernel<1, float>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+            else hipLaunchKernelGGL((node3_kernel<2, float>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+            return;
+        }
+        const double* A = c.A.vals;
+        if (mode == 0) hipLaunchKernelGGL((node3_kernel<0, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+        else if (mode == 1) hipLaunchKernelGGL((node3_kernel<1, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+        else hipLaunchKernelGGL((node3_kernel<2, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
     };
     for (int k = 0; k + 1 < nl; ++k) {
         fep_solver::Level& c = L[k];
