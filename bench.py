@@ -250,10 +250,12 @@ def run(args):
                     ev_done[i].record(comm)
 
         if args.preheat_ms > 0:                         # clock ramp: not part of W, not timed (reported as `preheat_ms`)
+            # LOCAL kernels only: a loop bounded by wall time runs a different number of passes on every rank, so it must not
+            # hold a collective (the interface exchange of step() would leave the ranks waiting for each other for good)
             t_h = time.perf_counter()
             while time.perf_counter() - t_h < args.preheat_ms * 1e-3:
                 for _ in range(50):
-                    step()
+                    shard.step(stream, 0, full)
                 torch.cuda.synchronize()
         for _ in range(warmup):
             step()
@@ -414,7 +416,9 @@ def run(args):
     # EVERY kernel, which costs 2-5 us per pair and serialises the launches (its sum is 5-12 % above the stream time).
     timing = f'HIP events in situ around every kernel, mean of {n_prof} launches'
     k_ms_split = k_ms
-    if (et == 'P1' and route == 'node') or (et != 'P1' and patch_form):
+    # N > 1: the launch stream also waits for the interface exchange of two passes earlier (double-buffered force vector), which
+    # is not kernel time: the per-kernel event pairs stay the priced duration there.
+    if world == 1 and ((et == 'P1' and route == 'node') or (et != 'P1' and patch_form)):
         k_ms = stream_ms
         timing = (f'HIP events on the launch stream around the {args.steps} timed steps / {args.steps} (the step\'s kernels back to '
                   f'back); kernels_ms: a second pass with an event pair around every kernel (sum {k_ms_split:.4f} ms)')
@@ -483,8 +487,11 @@ def run(args):
                     print(f'[bench] parity against the oracle outside the stated tolerance: {errs}', file=sys.stderr)
         print(json.dumps(line), flush=True)
         try:        # the box's clocks next to the line (stderr): runs of the same binary differ by ~10 % between boxes of the pool
+            # (a profiler's preloaded library must not ride into the child: with --pmc it starts the GPU runtime in every process it
+            # is loaded into, and rocm-smi — an `env python3` script — would then replace a GPU-initialised process, which the box refuses)
+            env_smi = {k: v for k, v in os.environ.items() if k != 'LD_PRELOAD' and not k.startswith(('ROCP', 'ROCPROF'))}
             smi = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                                 text=True, timeout=20).stdout
+                                 text=True, timeout=20, env=env_smi).stdout
             keep = [l.strip() for l in smi.splitlines() if 'GPU[0]' in l and any(k in l for k in ('sclk', 'mclk', 'fclk', 'Power'))]
             print('[bench] ' + ' | '.join(keep), file=sys.stderr)
         except Exception as exc:                                        # rocm-smi missing or refused: the line stands

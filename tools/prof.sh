@@ -18,3 +18,6 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_V
 python3 tools/summarize_counters.py $tag $out $extra
 # the summaries land in profiles/ of THIS checkout; on a gpurun box only gpurun_out/ travels back: leave copies there
 cp profiles/${tag}_kernel_stats.csv profiles/${tag}_counters.csv $out/ 2>/dev/null || true
+if [ "$extra" == "--traffic-latest" ]; then cp profiles/traffic_latest.json $out/ 2>/dev/null || true; fi
+# the raw traces do not travel (gpurun merges at most 64 MiB back; bench.py's pre-heat alone leaves thousands of launches in each)
+rm -rf $out/stats $out/fetch $out/write $out/sq $out/sq2
