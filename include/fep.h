@@ -233,6 +233,9 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
  * cycle in which level 0 is always the CURRENT tangent (k_data_d of the call) and the coarse operators stay those of the
  * reference matrix.  Smoother: degree-2 Chebyshev in D^-1 A on [lmax/20, lmax], lmax = 1.2 x the value the hierarchy's
  * omega encodes (omega = 4 / (3 * 1.05 * rho)); FEP_AMG_SMOOTHER=jacobi selects two damped block-Jacobi sweeps instead.
+ * The preconditioner reads single precision — K in the smoother's level-0 passes, the refreshed coarse operators
+ * (FEP_AMG_FP32=0: double), the transfers, applied in node blocks (FEP_AMG_BLOCK_TRANSFERS=0: the CSR forms as pushed) —;
+ * CG's own product, its vectors and the Galerkin products are double precision.
  *
  *   fep_solver_amg_push_level   transfer level k -> k+1 (k = number of levels pushed so far; level 0 = the mesh DOFs):
  *       P (n_fine x n_coarse) and R = P^T (n_coarse x n_fine) in CSR; A = operator of level k+1 (n_coarse^2, CSR) or,
@@ -244,7 +247,8 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
  *   fep_solver_amg_enable_refresh   after the last level: from now on every fep_solver_amg_pcg_dev first re-projects the
  *                               coarse operators from ITS k_data_d — A_1 = R_0 K P_0, A_2 = R_1 A_1 P_1, ... with the
  *                               transfers as pushed, block-Jacobi inverses and the coarsest inverse recomputed — instead of
- *                               keeping those of the reference matrix (numeric products on patterns fixed here, on the host:
+ *                               keeping those of the reference matrix (numeric products on patterns fixed here by the host;
+ *                               the terms of every output entry are listed on the device, FEP_AMG_PLAN=host: by the host too:
  *                               40 % fewer iterations on plastic tangents).  FEP_ERANGE: coarsest level > 256 DOFs (its inverse
  *                               is recomputed by one workgroup) or a product with more than 2^31 terms — the hierarchy is
  *                               left as pushed; an allocation failure drops it.
