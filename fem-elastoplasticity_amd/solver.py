@@ -165,7 +165,7 @@ def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8
             if M is not None:
                 M.sort_indices()
         out.append({'P': P, 'R': R, 'A': Aop, 'D': Dc, 'omega': 4.0 / (3.0 * 1.05 * rho), 'last': last,
-                    'size': (Ac.shape[0], Ac.nnz)})
+                    'size': (Ac.shape[0], Ac.nnz), 'Pt': Pt, 'rho': rho})      # (Pt, rho: offline studies, tools/transfer_study.py)
         if last:
             break
         A, xy, bs, Di = Ac, cxy, 3, Dc

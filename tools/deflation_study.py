@@ -14,88 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sol = importlib.import_module('fem-elastoplasticity_amd.solver')
 
 
-def cheb(omega, alpha=20.0, safety=1.2):
-    rho = 4.0 / (3.0 * 1.05 * omega)
-    lmax = safety * rho
-    lmin = lmax / alpha
-    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
-    sigma = theta / delta
-    r0 = 1.0 / sigma
-    r1 = 1.0 / (2.0 * sigma - r0)
-    return 1.0 / theta, 1.0 + r1 * r0, -r1 * r0, 2.0 * r1 / delta
-
-
-def smooth(A, Di, b, x0, ch):
-    c1, a2, cp, w2 = ch
-    if x0 is None:
-        x1 = c1 * (Di @ b)
-        return a2 * x1 + w2 * (Di @ (b - A @ x1))
-    x1 = x0 + c1 * (Di @ (b - A @ x0))
-    return a2 * x1 + cp * x0 + w2 * (Di @ (b - A @ x1))
-
-
-class VCycle:
-    def __init__(self, A0, levels):
-        self.A = [A0] + [lv['A'] for lv in levels]
-        self.Di = [sol._block_diag_inverse(A0, 2)] + [lv['D'] for lv in levels]
-        self.P = [lv['P'] for lv in levels]
-        self.R = [lv['R'] for lv in levels]
-        self.ch = [cheb(lv['omega']) for lv in levels]
-        self.nl = len(levels)
-
-    def __call__(self, b, k=0):
-        if k == self.nl:
-            return self.A[k] @ b                         # the coarsest operator is stored inverted
-        x = smooth(self.A[k], self.Di[k], b, None, self.ch[k])
-        r = b - self.A[k] @ x
-        x = x + self.P[k] @ self(self.R[k] @ r, k + 1)
-        return smooth(self.A[k], self.Di[k], b, x, self.ch[k])
-
-
-def pcg(A, M, b, rtol, max_iter=3000, W=None, keep=0):
-    """Returns (x, iterations, lanczos (alpha, beta), stored normalised z vectors).  W: deflation space (n, k)."""
-    if W is not None:
-        AW = A @ W
-        E = np.linalg.inv(W.T @ AW)
-        x = W @ (E @ (W.T @ b))
-    else:
-        x = np.zeros_like(b)
-    r = b - A @ x
-    z = M(r)
-    if W is not None:
-        z = z - W @ (E @ (AW.T @ z))
-    p = z.copy()
-    g = r @ z
-    bb = b @ b
-    al, be, Z = [], [], []
-    for it in range(1, max_iter + 1):
-        if keep and len(Z) < keep:
-            Z.append(z / np.sqrt(g))
-        q = A @ p
-        a = g / (p @ q)
-        x += a * p
-        r -= a * q
-        al.append(a)
-        if r @ r <= rtol * rtol * bb:
-            return x, it, (al, be), Z
-        z = M(r)
-        if W is not None:
-            z = z - W @ (E @ (AW.T @ z))
-        gn = r @ z
-        be.append(gn / g)
-        p = z + (gn / g) * p
-        g = gn
-    return x, max_iter, (al, be), Z
-
-
-def lanczos_T(al, be):
-    m = len(al)
-    T = np.zeros((m, m))
-    for j in range(m):
-        T[j, j] = 1.0 / al[j] + (be[j - 1] / al[j - 1] if j else 0.0)
-        if j + 1 < m:
-            T[j, j + 1] = T[j + 1, j] = -np.sqrt(be[j]) / al[j]      # for the UNSIGNED normalised z_j
-    return T
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from deflation_study_lib import VCycle, pcg, lanczos_T  # noqa: E402
 
 
 ap = argparse.ArgumentParser()
