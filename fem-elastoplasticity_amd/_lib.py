@@ -69,6 +69,9 @@ PROTOTYPES = {
     'fep_solver_amg_pcg_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                          C.c_int, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)]),
     'fep_aggregate_host': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, c_i64_p]),
+    'fep_spgemm_count_host': (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_spgemm_fill_host': (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_ctx_profile_begin': (C.c_int, [C.c_void_p]),
     'fep_ctx_profile_end': (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
 }

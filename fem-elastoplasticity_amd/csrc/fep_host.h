@@ -1404,6 +1404,72 @@ inline int product_pattern(int64_t n_rows, int64_t n_mid, int64_t n_cols, const 
     return FEP_OK;
 }
 
+// Numeric sparse product C = X * Y on the host, rows in parallel (the multigrid set-up's Galerkin products: SciPy's are single
+// threaded, 0.45 of the hierarchy's 1.3 s at 1 M DOFs).  Two calls: spgemm_count fills Cp (structural row sizes), spgemm_fill
+// the column ids (ascending per row) and values; entries whose terms cancel to zero are kept (the caller drops them).
+// Row i accumulates its terms in the order of X's entries, each Y row front to back (Gustavson), into a per-thread dense row.
+inline int spgemm_count(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* Xp, const int32_t* Xi, const int32_t* Yp,
+                        const int32_t* Yi, int32_t* Cp) {
+    if (n_rows < 0 || n_mid < 0 || n_cols < 0 || !Xp || !Yp || !Cp) return FEP_EINVAL;
+    std::atomic<int> bad{0};
+    std::vector<int32_t> cnt((size_t)n_rows, 0);
+    parallel_chunks(n_rows, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int64_t> mark((size_t)n_cols, -1);
+        for (int64_t i = lo; i < hi && !bad; ++i) {
+            int32_t c = 0;
+            for (int32_t x = Xp[i]; x < Xp[i + 1]; ++x) {
+                const int32_t j = Xi[x];
+                if (j < 0 || j >= n_mid) { bad = 1; return; }
+                for (int32_t y = Yp[j]; y < Yp[j + 1]; ++y) {
+                    const int32_t J = Yi[y];
+                    if (J < 0 || J >= n_cols) { bad = 1; return; }
+                    if (mark[(size_t)J] != i) { mark[(size_t)J] = i; ++c; }
+                }
+            }
+            cnt[(size_t)i] = c;
+        }
+    });
+    if (bad) return FEP_ERANGE;
+    int64_t tot = 0;
+    Cp[0] = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        tot += cnt[(size_t)i];
+        if (tot >= INT32_MAX) return FEP_ERANGE;
+        Cp[i + 1] = (int32_t)tot;
+    }
+    return FEP_OK;
+}
+
+inline int spgemm_fill(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* Xp, const int32_t* Xi, const double* Xv,
+                       const int32_t* Yp, const int32_t* Yi, const double* Yv, const int32_t* Cp, int32_t* Ci, double* Cv) {
+    if (n_rows < 0 || n_mid < 0 || n_cols < 0 || !Xp || !Yp || !Cp || (Cp[n_rows] > 0 && (!Ci || !Cv || !Xv || !Yv))) return FEP_EINVAL;
+    std::atomic<int> bad{0};
+    parallel_chunks(n_rows, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int64_t> mark((size_t)n_cols, -1);
+        std::vector<double> acc((size_t)n_cols, 0.0);
+        std::vector<int32_t> cols;
+        for (int64_t i = lo; i < hi && !bad; ++i) {
+            cols.clear();
+            for (int32_t x = Xp[i]; x < Xp[i + 1]; ++x) {
+                const int32_t j = Xi[x];
+                if (j < 0 || j >= n_mid) { bad = 1; return; }
+                const double xv = Xv[x];
+                for (int32_t y = Yp[j]; y < Yp[j + 1]; ++y) {
+                    const int32_t J = Yi[y];
+                    if (J < 0 || J >= n_cols) { bad = 1; return; }
+                    if (mark[(size_t)J] != i) { mark[(size_t)J] = i; cols.push_back(J); acc[(size_t)J] = xv * Yv[y]; }
+                    else acc[(size_t)J] += xv * Yv[y];
+                }
+            }
+            if ((int64_t)cols.size() != (int64_t)Cp[i + 1] - Cp[i]) { bad = 2; return; }      // Cp is not spgemm_count's of these factors
+            std::sort(cols.begin(), cols.end());
+            int32_t t = Cp[i];
+            for (int32_t J : cols) { Ci[t] = J; Cv[t] = acc[(size_t)J]; ++t; }
+        }
+    });
+    return bad == 1 ? FEP_ERANGE : bad == 2 ? FEP_EINVAL : FEP_OK;
+}
+
 struct ProductPlan {
     std::vector<int32_t> tptr, xa, ya;       // terms of output entry c: xa / ya [tptr[c] .. tptr[c+1])
 };

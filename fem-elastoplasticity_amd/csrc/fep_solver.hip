@@ -1569,3 +1569,28 @@ extern "C" int fep_aggregate_host(int64_t n, const int32_t* indptr, const int32_
         return FEP_EINVAL;
     }
 }
+
+// Host sparse product for the multigrid set-up (fep_host.h spgemm_count / spgemm_fill): no GPU involved.
+extern "C" int fep_spgemm_count_host(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* x_indptr, const int32_t* x_indices,
+                                     const int32_t* y_indptr, const int32_t* y_indices, int32_t* c_indptr_out) {
+    try {
+        return fep_host::spgemm_count(n_rows, n_mid, n_cols, x_indptr, x_indices, y_indptr, y_indices, c_indptr_out);
+    } catch (const std::bad_alloc&) {
+        return FEP_ENOMEM;
+    } catch (...) {
+        return FEP_EINVAL;
+    }
+}
+
+extern "C" int fep_spgemm_fill_host(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* x_indptr, const int32_t* x_indices,
+                                    const double* x_vals, const int32_t* y_indptr, const int32_t* y_indices, const double* y_vals,
+                                    const int32_t* c_indptr, int32_t* c_indices_out, double* c_vals_out) {
+    try {
+        return fep_host::spgemm_fill(n_rows, n_mid, n_cols, x_indptr, x_indices, x_vals, y_indptr, y_indices, y_vals, c_indptr,
+                                     c_indices_out, c_vals_out);
+    } catch (const std::bad_alloc&) {
+        return FEP_ENOMEM;
+    } catch (...) {
+        return FEP_EINVAL;
+    }
+}

@@ -104,6 +104,30 @@ def _stream(torch, device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _spgemm(X, Y):
+    """X @ Y for CSR factors through fep_spgemm_*_host (rows in parallel on the host's cores; SciPy's product is one thread),
+    numerically-zero entries dropped as SciPy's product drops them; column ids ascending."""
+    X, Y = ssp.csr_matrix(X), ssp.csr_matrix(Y)
+    if X.shape[1] != Y.shape[0]:
+        raise ValueError('shapes do not match')
+    n, m, k = X.shape[0], X.shape[1], Y.shape[1]
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    xp, xi, xv, yp, yi, yv = i32(X.indptr), i32(X.indices), f64(X.data), i32(Y.indptr), i32(Y.indices), f64(Y.data)
+    cp = np.empty(n + 1, dtype=np.int32)
+    l = _lib.lib()
+    _lib.check(l.fep_spgemm_count_host(n, m, k, _lib.ptr(xp), _lib.ptr(xi), _lib.ptr(yp), _lib.ptr(yi), _lib.ptr(cp)),
+               'fep_spgemm_count_host')
+    ci = np.empty(int(cp[n]), dtype=np.int32)
+    cv = np.empty(int(cp[n]), dtype=np.float64)
+    _lib.check(l.fep_spgemm_fill_host(n, m, k, _lib.ptr(xp), _lib.ptr(xi), _lib.ptr(xv), _lib.ptr(yp), _lib.ptr(yi), _lib.ptr(yv),
+                                      _lib.ptr(cp), _lib.ptr(ci), _lib.ptr(cv)), 'fep_spgemm_fill_host')
+    Cm = ssp.csr_matrix((cv, ci, cp), shape=(n, k))
+    Cm.has_sorted_indices = True
+    Cm.eliminate_zeros()
+    return Cm
+
+
 def _masked_operator(K, f):
     """Q K Q + (I - Q) without explicit zeros — what `(Dq @ K @ Dq + diags(1 - f)).tocsr()` returns, entry for entry, without
     the two sparse products and their temporaries (2.1 of the hierarchy's 7 s at 1 M DOFs): rows and columns of the few
@@ -150,11 +174,10 @@ def build_amg_hierarchy(K, free_dof, coordinates, coarse_nodes=400, max_levels=8
         Pt, cxy = _tentative(agg, na, xy, bs)
         if bs == 2:
             Pt = (Dq @ Pt).tocsr()                       # constrained DOFs neither interpolate nor receive
-        P = (Pt - (4.0 / (3.0 * rho)) * (Di @ (A @ Pt))).tocsr()
-        Ac = (P.T @ A @ P).tocsr()
-        Ac.sum_duplicates()
-        last = na <= coarse_nodes or level == max_levels - 1 or 3 * na > 0.7 * A.shape[0]
+        P = (Pt - (4.0 / (3.0 * rho)) * (Di @ _spgemm(A, Pt))).tocsr()
         R = P.T.tocsr()
+        Ac = _spgemm(R, _spgemm(A, P))                   # Galerkin operator (threaded host products; SciPy: (P.T @ A @ P))
+        last = na <= coarse_nodes or level == max_levels - 1 or 3 * na > 0.7 * A.shape[0]
         if last:
             dense = Ac.toarray()
             dense += 1e-10 * np.abs(dense).max() * np.eye(dense.shape[0])

@@ -268,6 +268,14 @@ int fep_solver_amg_pcg_dev(fep_solver* solver, void* stream, const double* k_dat
                            double rtol, int max_iter, int check_every, int* iters_out, double* relres_out,
                            int* state_out);
 int fep_aggregate_host(int64_t n, const int32_t* indptr, const int32_t* indices, int32_t* agg_out, int64_t* n_agg_out);
+/* Host sparse product C = X * Y for the set-up's Galerkin products (P^T A P with SciPy in the first versions; the reference has
+ * no multigrid: DP:1062-1066 is a dense solve), rows in parallel.  _count: structural row sizes into c_indptr_out (n_rows + 1);
+ * _fill: column ids ascending per row and values on that structure (entries that cancel to zero are kept).  No GPU involved. */
+int fep_spgemm_count_host(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* x_indptr, const int32_t* x_indices,
+                          const int32_t* y_indptr, const int32_t* y_indices, int32_t* c_indptr_out);
+int fep_spgemm_fill_host(int64_t n_rows, int64_t n_mid, int64_t n_cols, const int32_t* x_indptr, const int32_t* x_indices,
+                         const double* x_vals, const int32_t* y_indptr, const int32_t* y_indices, const double* y_vals,
+                         const int32_t* c_indptr, int32_t* c_indices_out, double* c_vals_out);
 
 /* ---- in-situ kernel timing (bench.py's roofline figure) --------------------------------
  * Between fep_ctx_profile_begin and fep_ctx_profile_end every fep_step_dev / fep_assemble_dev call

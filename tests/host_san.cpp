@@ -193,6 +193,18 @@ int main(int argc, char** argv) {
         }
         std::printf("product plans: rc %d terms %zu + %zu worst %.2e\n", pr, h1.xa.size(), h2.xa.size(), worst);
         if (pr != FEP_OK || worst > 1e-13) rc = 1;
+        // the threaded numeric product of the set-up (spgemm_count / spgemm_fill) on the same factors: T = A P has the
+        // pattern of product_pattern and the values of the plan, summed in the same order (bitwise)
+        if (pr == FEP_OK) {
+            std::vector<int32_t> Sp((size_t)n_n + 1), Si;
+            std::vector<double> Sv, Tv(Ti.size());
+            for (size_t c = 0; c < Tv.size(); ++c) { double a = 0; for (int32_t t = h1.tptr[c]; t < h1.tptr[c + 1]; ++t) a += Av[(size_t)h1.xa[(size_t)t]] * Pv[(size_t)h1.ya[(size_t)t]]; Tv[c] = a; }
+            int sr = spgemm_count(n_n, n_n, n_agg, Ap, Ai, Pp.data(), Pi.data(), Sp.data());
+            if (sr == FEP_OK) { Si.resize((size_t)Sp[(size_t)n_n]); Sv.resize(Si.size()); sr = spgemm_fill(n_n, n_n, n_agg, Ap, Ai, Av.data(), Pp.data(), Pi.data(), Pv.data(), Sp.data(), Si.data(), Sv.data()); }
+            const bool same = sr == FEP_OK && Sp == Tp && Si == Ti && Sv == Tv;
+            std::printf("spgemm: rc %d entries %zu identical to the plan's product %d\n", sr, Si.size(), (int)same);
+            if (!same) rc = 1;
+        }
     }
     std::printf("result %s\n", rc ? "FAILED" : "ok");
     return rc;

@@ -72,3 +72,33 @@ def test_aggregates_from_concatenated_rows():
         agg_ref, na_ref = _aggregate_reference(A, bs)
         assert na == na_ref and np.array_equal(agg, agg_ref)
         assert agg.min() == 0 and agg.max() == na - 1
+
+
+def test_host_sparse_product_is_scipys():
+    """fep_spgemm_count_host / _fill_host (rows in parallel) against SciPy's product: same pattern once the cancelled entries
+    are dropped, column ids ascending, values to rounding (the association inside a row is SciPy's: X's entries in order)."""
+    rng = np.random.default_rng(7)
+    for shape_x, shape_y, dens in (((300, 200), (200, 150), 0.03), ((1, 5), (5, 1), 1.0), ((50, 40), (40, 60), 0.0),
+                                   ((2000, 2000), (2000, 300), 0.004)):
+        X = ssp.random(*shape_x, density=dens, random_state=int(rng.integers(1 << 30)), format='csr')
+        Y = ssp.random(*shape_y, density=dens, random_state=int(rng.integers(1 << 30)), format='csr')
+        Cm = solver._spgemm(X, Y)
+        ref = (X @ Y).tocsr()
+        ref.sort_indices()
+        assert Cm.shape == ref.shape and Cm.has_sorted_indices
+        assert np.array_equal(Cm.indptr, ref.indptr) and np.array_equal(Cm.indices, ref.indices)
+        if ref.nnz:
+            assert np.abs(Cm.data - ref.data).max() <= 1e-14 * np.abs(ref.data).max()
+    # exact cancellation: the structural entry is dropped like SciPy drops it
+    X = ssp.csr_matrix(np.array([[1.0, 1.0], [0.0, 2.0]]))
+    Y = ssp.csr_matrix(np.array([[1.0, 3.0], [-1.0, 0.5]]))
+    Cm = solver._spgemm(X, Y)
+    assert Cm.nnz == 3 and np.array_equal(Cm.toarray(), X.toarray() @ Y.toarray())
+    # out-of-range column ids are refused, not followed
+    ip = np.array([0, 1], dtype=np.int32)
+    bad = np.array([5], dtype=np.int32)
+    cp = np.empty(2, dtype=np.int32)
+    l = _lib.lib()
+    assert l.fep_spgemm_count_host(1, 1, 1, _lib.ptr(ip), _lib.ptr(bad), _lib.ptr(ip), _lib.ptr(np.zeros(1, dtype=np.int32)),
+                                   _lib.ptr(cp)) == -5
+    assert l.fep_spgemm_count_host(1, 1, 1, None, None, None, None, None) == -1

@@ -1,22 +1,5 @@
-#!/bin/bash
-# Round-3 evidence, last session of the round (after the solver / set-up work and bench.py's pre-heat + stream-event roofline).
-# The element-route kernels are those of tools/evidence_r03.sh: its P2 / P4 counter passes and the elem_bench matrix stand.
-# Outputs under gpurun_out/ev3b/ (copied into profiles/ afterwards).
-out=gpurun_out/ev3b; mkdir -p $out
+out=gpurun_out/s7; mkdir -p $out
 export TMPDIR=/tmp
-# (second half: the first session of this script stopped at the 2-rank rehearsal — the pre-heat loop held the
-# interface exchange and the ranks ran different numbers of passes; fixed, see profiles/r03_ablation.md)
-FEP_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 > $out/bench_2rank_gloo_weak.json 2> $out/bench_2rank.err; echo "2-rank weak rc=$?"
-FEP_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --backend gloo --scaling strong --steps 10 --warmup 2 > $out/bench_2rank_gloo_strong.json 2>> $out/bench_2rank.err; echo "2-rank strong rc=$?"
-FEP_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --backend gloo --elem P2 --cells 708 --state random --scaling strong --steps 10 --warmup 2 > $out/bench_2rank_gloo_strong_p2.json 2>> $out/bench_2rank.err; echo "2-rank strong P2 rc=$?"
-tools/prof.sh r03_p1 --traffic-latest python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_p1.log 2>&1; tail -3 $out/prof_p1.log
-FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end.log 2>&1; echo "newton rc=$?"
-FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 --cold > $out/newton_end_to_end_cold.log 2>&1; echo "newton (cold) rc=$?"
-FEP_AMG_REFRESH=0 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end_elastic_coarse.log 2>&1; echo "newton (elastic coarse operators) rc=$?"
-FEP_AMG_FP32=0 FEP_AMG_BLOCK_TRANSFERS=0 FEP_AMG_PLAN=host FEP_PCG_FIXED_BATCH=1 FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end_switches_off.log 2>&1; echo "newton (this session's changes switched off) rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_nb -- python3 tools/newton_bench.py --inexact 1e-2 --steps 2 > $out/prof_newton.log 2>&1; find /tmp/prof_nb -name "*kernel_stats.csv" -exec cp {} $out/newton_kernel_stats.csv \;
-python tools/setup_bench.py > $out/setup_bench.log 2>&1
-rocm-smi --showclocks --showpower > $out/rocm_smi_after.txt 2>&1
-for f in $out/newton_end_to_end*.log; do echo $f; grep "setup:" $f | cut -c1-160; tail -1 $f | cut -c1-120 | sed 's/"newton_its.*//'; tail -1 $f | grep -o '"wall_s": [0-9.]*, "startup_s": [0-9.]*'; done
-
-du -sh gpurun_out
+timeout -k 10 1000 python -m pytest tests/test_solver_gpu.py tests/test_newton_gpu.py -x -q -m gpu > $out/pytest.log 2>&1; echo "rc $?" >> $out/pytest.log; tail -4 $out/pytest.log
+for v in "A=1" "A=1"; do echo "== $v" >> $out/newton_ab.log; env $v FEP_VERBOSE=1 timeout -k 10 300 python tools/newton_bench.py --inexact 1e-2 2>&1 | grep "setup:\|set-up\|wall_s" | cut -c1-300 | sed 's/"newton_its.*"wall_s"/"wall_s"/' >> $out/newton_ab.log; done; cat $out/newton_ab.log
+timeout -k 10 200 python tools/amg_setup_profile.py > $out/amg_profile.log 2>&1; grep -v "^$" $out/amg_profile.log | head -32
