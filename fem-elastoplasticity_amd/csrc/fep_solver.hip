@@ -627,6 +627,123 @@ node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __
     }
 }
 
+// The bottom of the V-cycle in ONE workgroup: the last smoothed level (<= kTailNodes nodes) and the coarsest solve under it —
+// eight launches of a few microseconds each for a few hundred nodes (pre-smoothing x1, x2, residual, restriction, dense solve,
+// prolongation, post-smoothing x1, x2): at 1 M mesh DOFs 8 of the iteration's 38 launches and an eighth of its time.  The
+// level's vectors live in LDS, the operator (single precision, node3_kernel's layout) and the transfers' node blocks are read
+// from global memory (L2-resident: 146 KB) in every phase.  Same arithmetic as the launches it replaces: 8 lanes per node for
+// the operator passes, 8 per coarse node for the restriction, one per fine node for the prolongation.
+constexpr int kTailNodes = 384;            // three rounds of 128 nodes in a 1024-thread workgroup
+constexpr int kTailCoarse = 128;           // DOFs of the coarsest level
+struct TailArgs {
+    int n_nodes, n_c;                      // nodes of the level (3 DOFs each), DOFs of the coarsest level
+    const int32_t *nbp, *nbc; const float* A; const double* D;        // operator in node blocks, 3x3 block-Jacobi inverses
+    const int32_t *rptr, *rcol; const float* rval;                    // restriction to the coarsest level (Level::Blocks, BF = 3)
+    const int32_t *pptr, *pcol; const float* pval;                    // prolongation from it
+    const double* Ainv;                                               // dense inverse, row-major n_c x n_c
+    double c1, a2, cp, w2;                                            // Chebyshev coefficients of the level
+    const double* b; double* out;                                     // right-hand side in, smoothed iterate out (3 n_nodes)
+};
+
+// MODE as node3_kernel: 0: out = b - A x;  1: out = x + om D (b - A x);  2: out = ca x + cp xp + om D (b - A x)
+template <int MODE>
+__device__ inline void tail_pass(const TailArgs& a, const double* __restrict__ x, const double* __restrict__ b, double om, double ca,
+                                 double cp, const double* xp, double* __restrict__ out) {
+    const int sub = threadIdx.x & 7;
+    for (int n = threadIdx.x >> 3; n < ((a.n_nodes + 127) & ~127); n += 128) {          // (whole waves stay in the loop: shuffles)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (n < a.n_nodes) {
+            const int b0 = a.nbp[n], deg = a.nbp[n + 1] - b0;
+            const float* r0 = a.A + 9 * (int64_t)b0;
+            const float* r1 = r0 + 3 * deg;
+            const float* r2 = r1 + 3 * deg;
+            for (int t = sub; t < deg; t += 8) {
+                const double* xv = x + 3 * a.nbc[b0 + t];
+                const double x0 = xv[0], x1 = xv[1], x2 = xv[2];
+                s0 += (double)r0[3 * t] * x0 + (double)r0[3 * t + 1] * x1 + (double)r0[3 * t + 2] * x2;
+                s1 += (double)r1[3 * t] * x0 + (double)r1[3 * t + 1] * x1 + (double)r1[3 * t + 2] * x2;
+                s2 += (double)r2[3 * t] * x0 + (double)r2[3 * t + 1] * x1 + (double)r2[3 * t + 2] * x2;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (sub != 0 || n >= a.n_nodes) continue;
+        const double q0 = b[3 * n] - s0, q1 = b[3 * n + 1] - s1, q2 = b[3 * n + 2] - s2;
+        if (MODE == 0) { out[3 * n] = q0; out[3 * n + 1] = q1; out[3 * n + 2] = q2; continue; }
+        const double* d = a.D + 9 * n;
+        const double d0 = d[0] * q0 + d[1] * q1 + d[2] * q2, d1 = d[3] * q0 + d[4] * q1 + d[5] * q2, d2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
+        double o0 = x[3 * n], o1 = x[3 * n + 1], o2 = x[3 * n + 2];
+        if (MODE == 2) {
+            o0 *= ca; o1 *= ca; o2 *= ca;
+            if (xp) { o0 += cp * xp[3 * n]; o1 += cp * xp[3 * n + 1]; o2 += cp * xp[3 * n + 2]; }
+        }
+        out[3 * n] = o0 + om * d0; out[3 * n + 1] = o1 + om * d1; out[3 * n + 2] = o2 + om * d2;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+tail_kernel(TailArgs a) {
+    __shared__ double B[3 * kTailNodes], X[3 * kTailNodes], T[3 * kTailNodes], R[3 * kTailNodes];
+    __shared__ double bc[kTailCoarse], xc[kTailCoarse];
+    const int nd = 3 * a.n_nodes;
+    for (int i = threadIdx.x; i < nd; i += 1024) B[i] = a.b[i];
+    __syncthreads();
+    // x1 = c1 D b
+    for (int n = threadIdx.x; n < a.n_nodes; n += 1024) {
+        const double* d = a.D + 9 * n;
+        const double q0 = B[3 * n], q1 = B[3 * n + 1], q2 = B[3 * n + 2];
+        X[3 * n] = a.c1 * (d[0] * q0 + d[1] * q1 + d[2] * q2);
+        X[3 * n + 1] = a.c1 * (d[3] * q0 + d[4] * q1 + d[5] * q2);
+        X[3 * n + 2] = a.c1 * (d[6] * q0 + d[7] * q1 + d[8] * q2);
+    }
+    __syncthreads();
+    tail_pass<2>(a, X, B, a.w2, a.a2, 0.0, nullptr, T);                 // x2 = a2 x1 + w2 D (b - A x1)
+    __syncthreads();
+    tail_pass<0>(a, T, B, 0.0, 0.0, 0.0, nullptr, R);                   // r = b - A x2
+    __syncthreads();
+    {   // bc = R r: 8 lanes per coarse node
+        const int sub = threadIdx.x & 7, ncn = a.n_c / 3;
+        for (int J = threadIdx.x >> 3; J < ((ncn + 7) & ~7); J += 128) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            if (J < ncn)
+                for (int t = a.rptr[J] + sub, e = a.rptr[J + 1]; t < e; t += 8) {
+                    const double* ri = R + 3 * a.rcol[t];
+                    const float* v = a.rval + 9 * (int64_t)t;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { const double rv = ri[q]; s0 += (double)v[q] * rv; s1 += (double)v[3 + q] * rv; s2 += (double)v[6 + q] * rv; }
+                }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (J < ncn && sub == 0) { bc[3 * J] = s0; bc[3 * J + 1] = s1; bc[3 * J + 2] = s2; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_c; i += 1024) {                   // xc = A^-1 bc
+        const double* row = a.Ainv + (int64_t)i * a.n_c;
+        double v = 0.0;
+        for (int j = 0; j < a.n_c; ++j) v += row[j] * bc[j];
+        xc[i] = v;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < a.n_nodes; n += 1024) {               // x0 = x2 + P xc
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+        for (int t = a.pptr[n], e = a.pptr[n + 1]; t < e; ++t) {
+            const double* xj = xc + 3 * a.pcol[t];
+            const float* v = a.pval + 9 * (int64_t)t;
+            p0 += (double)v[0] * xj[0] + (double)v[1] * xj[1] + (double)v[2] * xj[2];
+            p1 += (double)v[3] * xj[0] + (double)v[4] * xj[1] + (double)v[5] * xj[2];
+            p2 += (double)v[6] * xj[0] + (double)v[7] * xj[1] + (double)v[8] * xj[2];
+        }
+        T[3 * n] += p0; T[3 * n + 1] += p1; T[3 * n + 2] += p2;
+    }
+    __syncthreads();
+    tail_pass<1>(a, T, B, a.c1, 1.0, 0.0, nullptr, X);                  // x1 = x0 + c1 D (b - A x0)
+    __syncthreads();
+    tail_pass<2>(a, X, B, a.w2, a.a2, a.cp, T, R);                      // x2 = a2 x1 + cp x0 + w2 D (b - A x1)
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd; i += 1024) a.out[i] = R[i];
+}
+
 // Coarsest operator (n <= kDenseMax, symmetric positive definite after the shift solver.py applies: 1e-10 of its largest
 // entry on the diagonal): inverted in place by one workgroup, Gauss-Jordan without pivoting, a fixed order.
 constexpr int kDenseMax = 256;             // (one workgroup: 1 ms at 128 DOFs, 7 ms at 256, 0.3 s at 900)
@@ -708,6 +825,7 @@ struct fep_solver {
     // first comparison of the round looked at the whole wall, set-up jitter included, and saw 1 %).  On; FEP_AMG_FP32=0 turns it off.
     float* k32 = nullptr;
     bool fp32 = true;
+    bool tail = true;                         // bottom of the V-cycle in one workgroup (tail_kernel; FEP_AMG_TAIL=0: the launches it replaces)
     bool block_transfers = true;              // Level::Blocks for the V-cycle's transfers (FEP_AMG_BLOCK_TRANSFERS=0: the CSR forms)
     // smoother of the V-cycle: degree-2 Chebyshev (default) or two damped block-Jacobi sweeps (FEP_AMG_SMOOTHER=jacobi)
     bool cheb = true;
@@ -807,6 +925,7 @@ static int solver_create_impl(fep_solver** out, int device_id, int64_t n_n, cons
     if (const char* al = std::getenv("FEP_AMG_CHEB_ALPHA")) { const double v = std::atof(al); if (v > 1.0) s->cheb_alpha = v; }
     if (const char* f32 = std::getenv("FEP_AMG_FP32")) s->fp32 = std::strcmp(f32, "0") != 0;
     if (const char* bt = std::getenv("FEP_AMG_BLOCK_TRANSFERS")) s->block_transfers = std::strcmp(bt, "0") != 0;
+    if (const char* tl = std::getenv("FEP_AMG_TAIL")) s->tail = std::strcmp(tl, "0") != 0;
     if (const char* sf = std::getenv("FEP_AMG_CHEB_SAFETY")) { const double v = std::atof(sf); if (v >= 1.0) s->cheb_safety = v; }
     s->device = device_id; s->n_n = n_n; s->n_dof = n_dof; s->n_blk = n_blk;
     s->ip0.assign(indptr_h, indptr_h + n_dof + 1);
@@ -1459,9 +1578,31 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
         else if (mode == 1) hipLaunchKernelGGL((node3_kernel<1, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
         else hipLaunchKernelGGL((node3_kernel<2, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
     };
+    // the last smoothed level and the coarsest solve under it in one launch when they are small enough (tail_kernel)
+    int kt = -1;
+    if (s->tail && n3 && nl >= 2) {
+        const fep_solver::Level &c = L[nl - 2], &lst = L[nl - 1];
+        if (c.A32 && c.n_coarse / 3 <= kTailNodes && lst.n_coarse <= kTailCoarse && lst.n_coarse % 3 == 0 && lst.tb.bf == 3 &&
+            lst.tb.nf == c.n_coarse / 3 && lst.A.nnz == lst.n_coarse * lst.n_coarse)
+            kt = nl - 2;
+    }
     for (int k = 0; k + 1 < nl; ++k) {
         fep_solver::Level& c = L[k];
         const Cheb ch = cheb_coefficients(L[k + 1].omega, s->cheb_alpha, s->cheb_safety);
+        if (k == kt) {
+            const fep_solver::Level& lst = L[nl - 1];
+            TailArgs ta;
+            ta.n_nodes = (int)(c.n_coarse / 3); ta.n_c = (int)lst.n_coarse;
+            ta.nbp = c.nbp; ta.nbc = c.nbc; ta.A = c.A32; ta.D = c.D.vals;
+            ta.rptr = lst.tb.rptr; ta.rcol = lst.tb.rcol; ta.rval = lst.tb.rval;
+            ta.pptr = lst.tb.pptr; ta.pcol = lst.tb.pcol; ta.pval = lst.tb.pval;
+            ta.Ainv = lst.A.vals;
+            ta.c1 = ch.c1; ta.a2 = ch.a2; ta.cp = ch.cp; ta.w2 = ch.w2;
+            ta.b = c.b; ta.out = c.r;
+            hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(1024), 0, st, ta);
+            c.xcur = c.r;
+            break;
+        }
         csr_apply(st, c.D, c.b, nullptr, 0.0, ch.c1, c.x);           // x1 = c1 D b
         if (n3) {
             node3(2, c, c.x, ch.w2, ch.a2, 0.0, nullptr, c.t);       // x2 = a2 x1 + w2 D (b - A x1)
@@ -1475,9 +1616,11 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
         }
         restrict_apply(st, L[k + 1], c.r, L[k + 1].b);
     }
-    csr_apply(st, L[nl - 1].A, L[nl - 1].b, nullptr, 0.0, 1.0, L[nl - 1].x);
-    L[nl - 1].xcur = L[nl - 1].x;
-    for (int k = nl - 2; k >= 0; --k) {
+    if (kt < 0) {
+        csr_apply(st, L[nl - 1].A, L[nl - 1].b, nullptr, 0.0, 1.0, L[nl - 1].x);
+        L[nl - 1].xcur = L[nl - 1].x;
+    }
+    for (int k = kt >= 0 ? kt - 1 : nl - 2; k >= 0; --k) {
         fep_solver::Level& c = L[k];
         const Cheb ch = cheb_coefficients(L[k + 1].omega, s->cheb_alpha, s->cheb_safety);
         prolong_apply(st, L[k + 1], L[k + 1].xcur, c.xcur);         // x0 = x + P x_coarse

@@ -172,6 +172,32 @@ def test_refresh_terms_listed_on_the_device_are_the_host_plan(fep, et, n, monkey
 
 
 @pytest.mark.parametrize('et,n', [('P1', 64), ('Q2', 12)])
+def test_bottom_of_the_cycle_in_one_workgroup(fep, et, n, monkeypatch):
+    """tail_kernel runs the last smoothed level and the coarsest solve under it in one launch; FEP_AMG_TAIL=0 keeps the eight
+    launches it replaces.  The same operations (the block-Jacobi step's sums are associated differently): the same iteration
+    counts, solutions to 1e-9, each form bit-reproducible."""
+    mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
+    K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
+    b = rng.normal(size=ctx.n_dof)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('FEP_AMG_TAIL', mode)
+        sol = fep.KrylovSolver(ctx, qf)
+        sol.setup_amg(K_el, mesh['coordinates'], coarse_nodes=30)
+        assert sol.amg_refresh and sol.amg_levels[-2][0] <= 3 * 384          # the tail's precondition holds on these meshes
+        res = []
+        for K in (K_el, r['K']):
+            x = sol.solve_host(K, b, rtol=1e-11)
+            assert sol.last['state'] == 1 and np.array_equal(x, sol.solve_host(K, b, rtol=1e-11))
+            res.append((x, sol.last['iters']))
+        out[mode] = res
+        sol.close()
+    for (xt, itt), (xl, itl) in zip(out['1'], out['0']):
+        assert abs(itt - itl) <= 1 and relerr(xt, xl) <= 1e-9
+    ctx.close()
+
+
+@pytest.mark.parametrize('et,n', [('P1', 64), ('Q2', 12)])
 def test_block_transfers_are_the_csr_transfers_in_single_precision(fep, et, n, monkeypatch):
     """The V-cycle applies its transfers in node blocks with single-precision values (prolong_block_kernel /
     restrict_block_kernel); FEP_AMG_BLOCK_TRANSFERS=0 keeps the double-precision CSR forms.  The same preconditioner up to seven
