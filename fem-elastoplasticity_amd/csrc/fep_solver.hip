@@ -1099,27 +1099,44 @@ extern "C" int fep_solver_amg_push_level(fep_solver* s, int64_t n_fine, int64_t 
 static int build_transfer_blocks(fep_solver::Level& l, int bf, const int32_t* Pp, const int32_t* Pi, const double* Pv) {
     if (l.n_fine % bf || l.n_coarse % 3) return FEP_OK;
     const int64_t nf = l.n_fine / bf, nc = l.n_coarse / 3;
-    std::vector<int32_t> pptr((size_t)nf + 1, 0), pcol, cols;
+    // two passes over the fine nodes on the host's cores: blocks per node, then (after the running sum) their ids and values
+    std::vector<int32_t> pptr((size_t)nf + 1, 0), pcol;
     std::vector<float> pval;
-    for (int64_t i = 0; i < nf; ++i) {
+    std::atomic<int> bad{0};
+    auto node_cols = [&](int64_t i, std::vector<int32_t>& cols) {
         cols.clear();
         for (int32_t t = Pp[bf * i]; t < Pp[bf * i + bf]; ++t) {
-            if (Pi[t] < 0 || Pi[t] >= l.n_coarse) return FEP_ERANGE;
+            if (Pi[t] < 0 || Pi[t] >= l.n_coarse) { bad = 1; return; }
             cols.push_back(Pi[t] / 3);
         }
         std::sort(cols.begin(), cols.end());
         cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-        const size_t b0 = pcol.size();
-        pcol.insert(pcol.end(), cols.begin(), cols.end());
-        pval.resize(pcol.size() * (size_t)(3 * bf), 0.0f);
-        for (int r = 0; r < bf; ++r)
-            for (int32_t t = Pp[bf * i + r]; t < Pp[bf * i + r + 1]; ++t) {
-                const size_t b = b0 + (size_t)(std::lower_bound(cols.begin(), cols.end(), Pi[t] / 3) - cols.begin());
-                pval[b * (size_t)(3 * bf) + (size_t)(3 * r + Pi[t] % 3)] = (float)Pv[t];
-            }
-        if (pcol.size() >= (size_t)INT32_MAX / 9) return FEP_ERANGE;
-        pptr[(size_t)i + 1] = (int32_t)pcol.size();
+    };
+    fep_host::parallel_chunks(nf, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> cols;
+        for (int64_t i = lo; i < hi && !bad; ++i) { node_cols(i, cols); pptr[(size_t)i + 1] = (int32_t)cols.size(); }
+    });
+    if (bad) return FEP_ERANGE;
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t t = (int64_t)pptr[(size_t)i] + pptr[(size_t)i + 1];
+        if (t >= INT32_MAX / 9) return FEP_ERANGE;
+        pptr[(size_t)i + 1] = (int32_t)t;
     }
+    pcol.resize((size_t)pptr[(size_t)nf]);
+    pval.assign(pcol.size() * (size_t)(3 * bf), 0.0f);
+    fep_host::parallel_chunks(nf, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> cols;
+        for (int64_t i = lo; i < hi; ++i) {
+            node_cols(i, cols);
+            const size_t b0 = (size_t)pptr[(size_t)i];
+            std::copy(cols.begin(), cols.end(), pcol.begin() + (std::ptrdiff_t)b0);
+            for (int r = 0; r < bf; ++r)
+                for (int32_t t = Pp[bf * i + r]; t < Pp[bf * i + r + 1]; ++t) {
+                    const size_t b = b0 + (size_t)(std::lower_bound(cols.begin(), cols.end(), Pi[t] / 3) - cols.begin());
+                    pval[b * (size_t)(3 * bf) + (size_t)(3 * r + Pi[t] % 3)] = (float)Pv[t];
+                }
+        }
+    });
     const size_t nblk = pcol.size();
     std::vector<int32_t> rptr((size_t)nc + 1, 0), rcol(nblk), fill;
     std::vector<float> rval(nblk * (size_t)(3 * bf));
