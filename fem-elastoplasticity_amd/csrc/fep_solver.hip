@@ -580,17 +580,19 @@ block3_inverse_kernel(int64_t n_nodes, const int32_t* __restrict__ d9, const dou
 // out never aliases x (neighbours read it); it may alias xp.
 // AV = float: the operator's single-precision copy (to_float_kernel after every refresh; the smoother need not see more than
 // seven digits of it — level 1 at 1 M mesh DOFs: 30 instead of 60 MB per pass, four passes per cycle).
-template <int MODE, typename AV>
+// PASSES nodes per lane group (independent accumulators, loads in flight): 4 on big levels, 1 where four would leave the chip
+// with a few hundred workgroups (level 1 at 1 M mesh DOFs: 56 k nodes = 439 workgroups of 128 nodes).
+template <int MODE, typename AV, int PASSES>
 __global__ void __launch_bounds__(TPB)
 node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __restrict__ nbc, const AV* __restrict__ A,
              const double* __restrict__ D, const double* __restrict__ x, const double* __restrict__ b, double om, double ca,
              double cp, const double* xp, double* out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 7, grp = lane >> 3;
-    const int64_t node0 = (int64_t)blockIdx.x * NODES_PER_BLOCK + (int64_t)wave * (NODES_PER_WAVE * SPMV_PASSES) + grp;
-    double acc[SPMV_PASSES][3];
+    const int64_t node0 = (int64_t)blockIdx.x * ((TPB / 64) * NODES_PER_WAVE * PASSES) + (int64_t)wave * (NODES_PER_WAVE * PASSES) + grp;
+    double acc[PASSES][3];
 #pragma unroll
-    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         const int64_t n = node0 + ps * NODES_PER_WAVE;
         acc[ps][0] = acc[ps][1] = acc[ps][2] = 0.0;
         if (n < n_nodes) {
@@ -608,7 +610,7 @@ node3_kernel(int64_t n_nodes, const int32_t* __restrict__ nbp, const int32_t* __
         }
     }
 #pragma unroll
-    for (int ps = 0; ps < SPMV_PASSES; ++ps) {
+    for (int ps = 0; ps < PASSES; ++ps) {
         double a0 = acc[ps][0], a1 = acc[ps][1], a2 = acc[ps][2];
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
@@ -1582,18 +1584,23 @@ double* vcycle_chebyshev(fep_solver* s, hipStream_t st, const double* K, const d
     auto node3 = [&](int mode, const fep_solver::Level& c, const double* x, double om, double ca, double cp, const double* xp,
                      double* out) {
         const int64_t nn = c.n_coarse / 3;
-        const dim3 g((unsigned)((nn + NODES_PER_BLOCK - 1) / NODES_PER_BLOCK));
+        // four nodes per lane group only where that still leaves a few thousand workgroups
+        const bool big = nn >= (int64_t)NODES_PER_BLOCK * 2048;
+        const int npb = big ? NODES_PER_BLOCK : NODES_PER_BLOCK / SPMV_PASSES;
+        const dim3 g((unsigned)((nn + npb - 1) / npb));
+#define FEP_NODE3(MODE_, AV_, A_)                                                                                                     \
+        do {                                                                                                                          \
+            if (big) hipLaunchKernelGGL((node3_kernel<MODE_, AV_, SPMV_PASSES>), g, tb, 0, st, nn, c.nbp, c.nbc, A_, c.D.vals, x, c.b, om, ca, cp, xp, out); \
+            else hipLaunchKernelGGL((node3_kernel<MODE_, AV_, 1>), g, tb, 0, st, nn, c.nbp, c.nbc, A_, c.D.vals, x, c.b, om, ca, cp, xp, out);               \
+        } while (0)
         if (c.A32) {
             const float* A = c.A32;
-            if (mode == 0) hipLaunchKernelGGL((node3_kernel<0, float>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
-            else if (mode == 1) hipLaunchKernelGGL((node3_kernel<1, float>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
-            else hipLaunchKernelGGL((node3_kernel<2, float>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+            if (mode == 0) FEP_NODE3(0, float, A); else if (mode == 1) FEP_NODE3(1, float, A); else FEP_NODE3(2, float, A);
             return;
         }
         const double* A = c.A.vals;
-        if (mode == 0) hipLaunchKernelGGL((node3_kernel<0, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
-        else if (mode == 1) hipLaunchKernelGGL((node3_kernel<1, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
-        else hipLaunchKernelGGL((node3_kernel<2, double>), g, tb, 0, st, nn, c.nbp, c.nbc, A, c.D.vals, x, c.b, om, ca, cp, xp, out);
+        if (mode == 0) FEP_NODE3(0, double, A); else if (mode == 1) FEP_NODE3(1, double, A); else FEP_NODE3(2, double, A);
+#undef FEP_NODE3
     };
     // the last smoothed level and the coarsest solve under it in one launch when they are small enough (tail_kernel)
     int kt = -1;
