@@ -1,10 +1,5 @@
-out=gpurun_out/ev3d; mkdir -p $out
+out=gpurun_out/s13; mkdir -p $out
 export TMPDIR=/tmp
-FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end.log 2>&1; echo "newton rc=$?"
-FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 --cold > $out/newton_end_to_end_cold.log 2>&1; echo "newton (cold) rc=$?"
-FEP_AMG_REFRESH=0 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end_elastic_coarse.log 2>&1; echo "newton (elastic coarse operators) rc=$?"
-FEP_AMG_FP32=0 FEP_AMG_BLOCK_TRANSFERS=0 FEP_AMG_PLAN=host FEP_PCG_FIXED_BATCH=1 FEP_AMG_TAIL=0 FEP_VERBOSE=1 python tools/newton_bench.py --inexact 1e-2 > $out/newton_end_to_end_switches_off.log 2>&1; echo "newton (switches off) rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_nb -- python3 tools/newton_bench.py --inexact 1e-2 --steps 2 > $out/prof_newton.log 2>&1; find /tmp/prof_nb -name "*kernel_stats.csv" -exec cp {} $out/newton_kernel_stats.csv \;
-for f in $out/newton_end_to_end*.log; do echo $f; grep "setup:\|set-up" $f | cut -c1-160; tail -1 $f | grep -o '"wall_s": [0-9.]*, "startup_s": [0-9.]*'; done
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout -k 10 1000 python -m pytest tests/test_solver_gpu.py -x -q -m gpu > $out/pytest.log 2>&1; echo "rc $?" >> $out/pytest.log; tail -4 $out/pytest.log
+for v in "A=1" "A=1"; do echo "== $v" >> $out/newton_ab.log; env $v FEP_VERBOSE=1 timeout -k 10 300 python tools/newton_bench.py --inexact 1e-2 2>&1 | grep "setup:\|wall_s" | cut -c1-300 | sed 's/"newton_its.*"wall_s"/"wall_s"/' >> $out/newton_ab.log; done; cat $out/newton_ab.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_nb -- python3 tools/newton_bench.py --inexact 1e-2 --steps 2 > $out/prof_newton.log 2>&1; find /tmp/prof_nb -name "*kernel_stats.csv" -exec cp {} $out/newton_kernel_stats.csv \; ; grep "block_residual\|to_float" $out/newton_kernel_stats.csv | cut -c1-70,330-420
