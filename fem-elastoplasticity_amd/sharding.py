@@ -6,6 +6,9 @@ interface vector, `torch.distributed`).  K stays sub-assembled: K = sum_r P_r^T 
 holding K_r on its local nodes (rows of interface nodes are partial sums) — what a distributed
 Krylov solver consumes with the same interface exchange on its products.
 
+`FEP_EXCHANGE=p2p` selects the neighbour-only form of that exchange (sends / receives between the ranks on the two sides
+of a cut, `Partition._exchange_p2p`); the all-reduce is the default.
+
 The reference has no parallelism of any kind; this module is new.
 """
 import numpy as np
@@ -35,9 +38,11 @@ class Partition:
         self.ranges = element_ranges(elements.shape[1], world)
         touch = np.zeros(n_n, dtype=np.int32)
         mine = None
+        per_rank = []
         for r, (lo, hi) in enumerate(self.ranges):
             nodes_r = np.unique(elements[:, lo:hi])
             touch[nodes_r] += 1
+            per_rank.append(nodes_r)
             if r == rank:
                 mine = nodes_r
         self.lo, self.hi = self.ranges[rank]
@@ -53,17 +58,69 @@ class Partition:
         self.iface_local_dofs = (2 * self.iface_local[:, None] + np.arange(2)[None, :]).ravel()
         self.iface_slot_dofs = (2 * self.iface_slot[:, None] + np.arange(2)[None, :]).ravel()
         self._t = None
+        # neighbour lists for the point-to-point form of the exchange: per rank that shares nodes with this one, the LOCAL DOFs of
+        # the shared nodes in ascending global node order (the same order on both sides of a cut)
+        self.neighbours = {}
+        for r, nodes_r in enumerate(per_rank):
+            if r == rank:
+                continue
+            shared = np.intersect1d(mine, nodes_r, assume_unique=True)
+            if shared.size:
+                loc = np.searchsorted(mine, shared)
+                self.neighbours[r] = (2 * loc[:, None] + np.arange(2)[None, :]).ravel()
+        self._p2p = None
 
     # ---- host-array exchange (NumPy; used by the gloo tests and small drivers) -----------------
     def exchange_force_host(self, F_local, group=None):
         import torch
         import torch.distributed as dist
+        if self.world > 1 and self._use_p2p():
+            t = torch.from_numpy(F_local)                             # (shares memory: updated in place)
+            self._exchange_p2p(t, group)
+            return F_local
         buf = torch.zeros(2 * self.n_iface, dtype=torch.float64)
         buf[torch.from_numpy(self.iface_slot_dofs)] = torch.from_numpy(F_local[self.iface_local_dofs])
         if self.world > 1:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         F_local[self.iface_local_dofs] = buf[torch.from_numpy(self.iface_slot_dofs)].numpy()
         return F_local
+
+    # ---- neighbour-only exchange (FEP_EXCHANGE=p2p): every cut is shared by the two ranks on its sides, so each rank sends its
+    # partial sums on the shared DOFs to exactly those ranks and receives theirs — bytes per rank independent of the world size,
+    # no collective over all ranks.  Contributions are added in ascending rank order (own included) on every rank that holds a
+    # DOF: the same bits everywhere, as the all-reduce gives.  One batch of sends / receives (ncclGroupStart / End under RCCL).
+    def _exchange_p2p(self, F_t, group=None, stage_host=False):
+        import torch
+        import torch.distributed as dist
+        if not self.neighbours:
+            return F_t
+        dev = F_t.device
+        if self._p2p is None or self._p2p[0] != dev:
+            idx = {r: torch.from_numpy(d.astype(np.int64)).to(dev) for r, d in self.neighbours.items()}
+            iface = torch.from_numpy(self.iface_local_dofs.astype(np.int64)).to(dev)
+            self._p2p = (dev, idx, iface)
+        _, idx, iface = self._p2p
+        xdev = torch.device('cpu') if stage_host else dev
+        send = {r: F_t[i].to(xdev).contiguous() for r, i in idx.items()}
+        recv = {r: torch.empty_like(send[r]) for r in idx}
+        ops = []
+        for r in sorted(idx):
+            ops.append(dist.P2POp(dist.isend, send[r], r, group))
+            ops.append(dist.P2POp(dist.irecv, recv[r], r, group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        own = F_t[iface]                                             # this rank's partial sums on its interface DOFs (a copy)
+        F_t[iface] = 0.0
+        for r in sorted(list(idx) + [self.rank]):                    # 0 + c_a + c_b + ...: ascending rank order on every holder
+            if r == self.rank:
+                F_t[iface] += own
+            else:
+                F_t[idx[r]] += recv[r].to(dev)
+        return F_t
+
+    def _use_p2p(self):
+        import os
+        return os.environ.get('FEP_EXCHANGE', 'allreduce') == 'p2p'
 
     # ---- device-resident exchange (torch tensors on the rank's GPU; RCCL) --------------------------
     def exchange_force_(self, F_local_t, group=None):
@@ -75,6 +132,8 @@ class Partition:
         import torch.distributed as dist
         from . import _lib
         dev = F_local_t.device
+        if self.world > 1 and self._use_p2p():
+            return self._exchange_p2p(F_local_t, group, stage_host=dist.get_backend(group) == 'gloo')
         if self._t is None:
             pack = np.full(2 * self.n_iface, -1, dtype=np.int32)
             pack[self.iface_slot_dofs] = self.iface_local_dofs

@@ -46,11 +46,12 @@ def _local_oracle(orc, elem, coord, U, d1, d2, wf):
     return K_t, F, cp
 
 
-def _worker(rank, world, port, q, t='P1'):
+def _worker(rank, world, port, q, t='P1', exchange='allreduce'):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ['FEP_EXCHANGE'] = exchange
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from oracle import fep_oracle as orc
     fep, elem, coord, U, d1, d2, wf = _problem(t)
@@ -58,15 +59,26 @@ def _worker(rank, world, port, q, t='P1'):
     K_r, F_r, _ = _local_oracle(orc, part.local_elements, coord[:, part.nodes], U[:, part.nodes], d1, d2, wf)
     F_partial = F_r.copy()
     part.exchange_force_host(F_r)
+    # both forms of the exchange on the same partial sums: bit-identical where a node has two holders (a + b either way); with
+    # more holders the all-reduce's association is the library's, the neighbour form's is by rank
+    other = F_partial.copy()
+    os.environ['FEP_EXCHANGE'] = 'p2p' if exchange == 'allreduce' else 'allreduce'
+    part.exchange_force_host(other)
+    os.environ['FEP_EXCHANGE'] = exchange
+    two = np.repeat(part.mult <= 2, 2)
+    assert np.array_equal(other[two], F_r[two]) and np.abs(other - F_r).max() <= 1e-15 * max(np.abs(F_r).max(), 1e-300)
+    assert set(part.neighbours) <= set(range(world)) - {rank} and all(d.size % 2 == 0 for d in part.neighbours.values())
     q.put((rank, part.nodes, F_r, F_partial, K_r.tocoo(), part.n_iface, part.iface_local.size))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('t,world', [('P1', 2), ('P1', 3), ('P2', 2)])
-def test_interface_force_allreduce_gloo(t, world):
+@pytest.mark.parametrize('t,world,exchange', [('P1', 2, 'allreduce'), ('P1', 3, 'allreduce'), ('P2', 2, 'allreduce'),
+                                              ('P1', 2, 'p2p'), ('P1', 3, 'p2p'), ('P2', 2, 'p2p'), ('P1', 4, 'p2p')])
+def test_interface_force_allreduce_gloo(t, world, exchange):
     """P2 (BASELINE configs[4]'s element type): a cut through a P2 mesh shares one row of vertex + midside nodes
-    (2 nx + 1 nodes) when it falls between two cell rows."""
+    (2 nx + 1 nodes) when it falls between two cell rows.  exchange = 'p2p': the neighbour-only form (FEP_EXCHANGE=p2p: sends
+    and receives between the ranks on the two sides of a cut, contributions added in ascending rank order)."""
     from oracle import fep_oracle as orc
     fep, elem, coord, U, d1, d2, wf = _problem(t)
     K_g, F_g, cp = _local_oracle(orc, elem, coord, U, d1, d2, wf)
@@ -74,7 +86,7 @@ def test_interface_force_allreduce_gloo(t, world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, t)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, t, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

@@ -191,8 +191,9 @@ def test_contexts_and_solvers_release_their_device_memory(fep):
     assert used() - base <= 64 << 20         # allocator granularity, not a per-cycle leak (five cycles allocate ~0.5 GB)
 
 
-@pytest.mark.parametrize('t,world', [('P1', 2), ('Q1', 2), ('P2', 2)])
-def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
+@pytest.mark.parametrize('t,world,exchange', [('P1', 2, 'allreduce'), ('Q1', 2, 'allreduce'), ('P2', 2, 'allreduce'),
+                                              ('P1', 3, 'p2p'), ('P2', 2, 'p2p')])
+def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world, exchange):
     """The product's multi-GPU path with real processes: `world` fresh processes share cuda:0 (gloo rendezvous), each
     runs ShardedContext.step_dev + exchange_force_ (pack kernel -> all-reduce -> unpack kernel) on two streams with a
     double-buffered force vector — the sequence bench.py --gpus N drives (tests/shard_worker.py).  After the exchange
@@ -207,7 +208,7 @@ def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', FEP_EXCHANGE=exchange)   # p2p: the neighbour-only form of the exchange
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shard_worker.py')
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path), t], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -224,6 +225,7 @@ def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
         assert p.returncode == 0, out[-3000:]
     fmax = np.abs(ref['F']).max()
     K_sum, counts, covered = None, np.zeros(2, dtype=np.int64), np.zeros(n_dof // 2, dtype=int)
+    n_ifaces = []
     for r in range(world):
         d = np.load(tmp_path / f'rank{r}.npz')
         dofs = (2 * d['nodes'][:, None] + np.arange(2)[None, :]).ravel()
@@ -235,7 +237,8 @@ def test_two_process_exchange_on_one_gpu(fep, tmp_path, t, world):
         K_sum = Kg if K_sum is None else K_sum + Kg
         counts += d['counts']
         covered[d['nodes']] += 1
-        assert int(d['n_iface']) == (covered > 1).sum() or r == 0
+        n_ifaces.append(int(d['n_iface']))
+    assert all(v == (covered > 1).sum() for v in n_ifaces)             # every rank knows the whole interface
     assert (covered >= 1).all() and (covered > 1).sum() == (81 if t == 'P2' else 41) * (world - 1)       # one node row per cut
     assert tuple(counts) == (ref['n_smooth'], ref['n_apex'])
     assert abs(K_sum - ref['K']).max() <= 1e-12 * np.abs(ref['K'].data).max()
