@@ -148,6 +148,10 @@ def parse_args():
     ap.add_argument('--cpu-cells', type=int, default=None,
                     help='cells per side of the CPU-baseline square (default: --cells for P1, min(--cells, 354) otherwise: a bounded sample)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
+    ap.add_argument('--exchange', choices=('allreduce', 'p2p'), default=os.environ.get('FEP_EXCHANGE', 'allreduce'),
+                    help='form of the interface exchange the HEADLINE uses at N > 1 (both are timed in the same run: `exchange`)')
+    ap.add_argument('--min-elements-per-rank', type=int, default=100000,
+                    help='the north_star gate: only as many ranks take elements as leaves each at least this many (0 = off)')
     return ap.parse_args()
 
 
@@ -169,9 +173,16 @@ def launch_ranks(n):
 class Shard:
     """One rank's part of a mesh: device context + device-resident state of the benchmark step."""
 
-    def __init__(self, fep, torch, mesh, rank, world, dev, scale, two_buffers, state='bands'):
-        self.sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=dev.index)   # element type from n_p
+    def __init__(self, fep, torch, mesh, rank, world, dev, scale, two_buffers, state='bands', exchange='allreduce', min_elements=0):
+        self.sh = fep.ShardedContext(mesh['elements'], mesh['coordinates'], rank, world, device=dev.index,   # element type from n_p
+                                     min_elements_per_rank=min_elements, exchange=exchange)
         ctx = self.ctx = self.sh.ctx
+        self.idle = ctx is None                         # a rank the gate left without elements: no kernels, zeros into the all-reduce
+        if self.idle:
+            self.n_int = 0
+            self.Fb = [torch.empty(0, dtype=torch.float64, device=dev) for _ in range(2 if two_buffers else 1)]
+            self.counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            return
         ctx.set_materials(*dp_materials())
         n_int = self.n_int = ctx.n_int
         # the field is a function of the GLOBAL node set (identical on every rank that shares a node)
@@ -188,6 +199,8 @@ class Shard:
 
     def step(self, stream, i=0, full=True):
         """full: every output of SURVEY 8d (s, ds, ind_p, K, F); else only what a Newton iterate reads (K, F)."""
+        if self.idle:
+            return
         self.ctx.step_dev(stream, self.U.data_ptr(), ep=self.Ep.data_ptr(), accept=False,
                           s=self.S.data_ptr() if full else 0, ds=self.DS.data_ptr() if full else 0,
                           ind_p=self.indp.data_ptr() if full else 0, k_data=self.Kd.data_ptr(),
@@ -228,25 +241,27 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(shard, steps, warmup, full=True):
+    def timed(shard, steps, warmup, full=True, xmode=args.exchange):
         """warmup untimed + EXACTLY `steps` timed passes between barrier+synchronize; max over ranks.
-        N > 1: the interface all-reduce of pass i runs on a second stream under pass i+1's kernels (the force
-        vector is double-buffered; a pass only waits for the exchange that last used its buffer)."""
+        N > 1: the interface exchange of pass i (xmode: 'allreduce' | 'p2p'; None = no exchange at all, the reference point
+        of the exposed share) runs on a second stream under pass i+1's kernels (the force vector is double-buffered; a pass
+        only waits for the exchange that last used its buffer)."""
         ev_done = [torch.cuda.Event() for _ in range(2)]
         ev_ready = [torch.cuda.Event() for _ in range(2)]
         state = {'i': 0}
+        xch = world > 1 and xmode is not None
 
         def step():
             i = state['i'] & 1 if world > 1 else 0
             state['i'] += 1
-            if world > 1 and state['i'] > 2:
+            if xch and state['i'] > 2:
                 main.wait_event(ev_done[i])
             shard.step(stream, i, full)
-            if world > 1:
+            if xch:
                 ev_ready[i].record(main)
                 comm.wait_event(ev_ready[i])
                 with torch.cuda.stream(comm):
-                    shard.sh.exchange_force_(shard.Fb[i])
+                    shard.sh.exchange_force_(shard.Fb[i], mode=xmode)
                     ev_done[i].record(comm)
 
         if args.preheat_ms > 0:                         # clock ramp: not part of W, not timed (reported as `preheat_ms`)
@@ -284,18 +299,41 @@ def run(args):
         barrier()
         return kms, n_prof
 
-    def exchange_ms(shard, reps=20):
+    def exchange_ms(shard, mode, reps=20):
+        """One exchange on its own (back to back on the comm stream, nothing to hide under): max over ranks."""
         if world == 1:
             return None
+        barrier()
         with torch.cuda.stream(comm):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            shard.sh.exchange_force_(shard.Fb[0])
+            shard.sh.exchange_force_(shard.Fb[0], mode=mode)
             a.record(comm)
             for _ in range(reps):
-                shard.sh.exchange_force_(shard.Fb[0])
+                shard.sh.exchange_force_(shard.Fb[0], mode=mode)
             b.record(comm)
         barrier()
-        return a.elapsed_time(b) / reps
+        t = torch.tensor([a.elapsed_time(b) / reps], **f64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def exchange_report(shard, dt_headline):
+        """Both forms of the interface exchange in the SAME run: the exchange alone, the step with it on
+        the second stream, and the step without any exchange — exposed = what the overlapped exchange adds to a step, hidden =
+        the rest of its own duration."""
+        if world == 1:
+            return None
+        other = 'p2p' if args.exchange == 'allreduce' else 'allreduce'
+        dt_other, _, _ = timed(shard, args.steps, args.warmup, xmode=other)
+        dt_none, _, _ = timed(shard, args.steps, args.warmup, xmode=None)
+        step_ms = {args.exchange: dt_headline / args.steps * 1e3, other: dt_other / args.steps * 1e3, 'none': dt_none / args.steps * 1e3}
+        alone = {m: exchange_ms(shard, m) for m in ('allreduce', 'p2p')}
+        exposed = {m: max(0.0, step_ms[m] - step_ms['none']) for m in ('allreduce', 'p2p')}
+        return {'headline': args.exchange, 'alone_ms': alone, 'step_ms': step_ms, 'exposed_ms': exposed,
+                'hidden_ms': {m: max(0.0, alone[m] - exposed[m]) for m in alone},
+                'bytes_per_rank': {'allreduce': 16 * shard.sh.n_iface, 'p2p': 8 * int(shard.sh.p2p_send_dofs.size)},
+                'neighbours_of_rank0': list(shard.sh.p2p_ranks),
+                'note': 'alone: back to back on the comm stream; step: exchange of pass i under the kernels of pass i+1 (two '
+                        'streams, double-buffered force); exposed = step - step without exchange; max over ranks'}
 
     def gather_ranks(v):
         t = torch.tensor(v, **f64)
@@ -308,7 +346,8 @@ def run(args):
     # ---- the headline run ------------------------------------------------------------------------------------
     strong = args.scaling == 'strong'
     mesh = fep.rect_mesh(N, N if strong else N * world, et, 10, 10 if strong else 10 * world)
-    shard = Shard(fep, torch, mesh, rank, world, dev, args.field_scale, world > 1, args.state)
+    shard = Shard(fep, torch, mesh, rank, world, dev, args.field_scale, world > 1, args.state, args.exchange,
+                  args.min_elements_per_rank)
     n_el_total = int(mesh['elements'].shape[1])
     n_total = n_el_total * NQ[et]                      # integration points = element*quadpt updates per step, all ranks
     dt, step, stream_ms = timed(shard, args.steps, args.warmup)
@@ -316,9 +355,13 @@ def run(args):
     if world > 1:
         dist.all_reduce(cnt)
     n_smooth, n_apex = [int(v) for v in cnt.cpu()]
-    kms, n_prof = per_kernel(shard, step, args.steps)
+    if shard.idle:
+        kms, n_prof = {'element': 0.0, 'csr': 0.0, 'force': 0.0}, 0
+        barrier()
+    else:
+        kms, n_prof = per_kernel(shard, step, args.steps)
     ranks_ms = gather_ranks([kms['element'], kms['csr'], kms['force']])
-    x_ms = exchange_ms(shard)
+    x_rep = exchange_report(shard, dt)
     n_int = shard.n_int
     ctx = shard.ctx
 
@@ -327,9 +370,20 @@ def run(args):
     if world == 1:
         dt_kf, step_kf, stream_ms_kf = timed(shard, args.steps, args.warmup, full=False)
         kms_kf, _ = per_kernel(shard, step_kf, args.steps)
+        # algorithmic bytes of a K,F-only step: every node's coordinates and displacement once (16 + 16 B),
+        # the previous plastic strain (32 B per point), the CSR values written once (8 B each), the force (16 B per node);
+        # static index data (element table, gather plan) excluded as in SURVEY 8d
+        n_nodes = ctx.n_dof // 2
+        kf_bytes = 32.0 * n_nodes + 32.0 * n_int + 8.0 * ctx.nnz + 16.0 * n_nodes
+        kf_ms = stream_ms_kf
         kf = {'ms_per_step': dt_kf / args.steps * 1e3, 'stream_ms_per_step': stream_ms_kf, 'updates_per_s': n_int * args.steps / dt_kf,
               'kernels_ms': {'point': kms_kf['element'], 'assembly': kms_kf['csr'], 'force': kms_kf['force']},
-              'note': 'fep_step_dev with s = ds = ind_p = counts = NULL (newton.py asks for K and F only)'}
+              'kernel': ctx.kernel_names(1),
+              'algorithmic_bytes': kf_bytes, 'GBps': kf_bytes / (kf_ms * 1e-3) / 1e9,
+              'frac': kf_bytes / (kf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              'algorithmic_bytes_formula': '32*n_nodes (xy + U) + 32*n_int (ep) + 8*nnz (K) + 16*n_nodes (F)',
+              'note': 'fep_step_dev with s = ds = ind_p = counts = NULL (newton.py asks for K and F only); frac = algorithmic '
+                      'bytes / stream_ms_per_step / 8 TB/s'}
 
     # the mesh-free entry point on its own (fep_return_map_dev: the drop-in for construct_constitutive_problem, DP:604-757):
     # strain, plastic strain and the four material arrays in, s / ds / ind_p / counts out = 193 B per point
@@ -367,28 +421,37 @@ def run(args):
     strong_line = None
     if world > 1 and not strong:
         mesh_s = fep.rect_mesh(N, N, et, 10, 10)
-        shard_s = Shard(fep, torch, mesh_s, rank, world, dev, args.field_scale, True, args.state)
+        shard_s = Shard(fep, torch, mesh_s, rank, world, dev, args.field_scale, True, args.state, args.exchange,
+                        args.min_elements_per_rank)
         dt_s, step_s, _ = timed(shard_s, args.steps, args.warmup)
-        kms_s, _ = per_kernel(shard_s, step_s, args.steps)
+        if shard_s.idle:
+            kms_s = {'element': 0.0, 'csr': 0.0}
+            barrier()
+        else:
+            kms_s, _ = per_kernel(shard_s, step_s, args.steps)
         rk = gather_ranks([kms_s['element'], kms_s['csr'], float(shard_s.n_int)])
         n_s = int(mesh_s['elements'].shape[1]) * NQ[et]
         strong_line = {'value': n_s * args.steps / dt_s, 'unit': 'updates/s', 'ms_per_step': dt_s / args.steps * 1e3,
-                       'elements_total': n_s, 'scaling': 'strong',
+                       'points_total': n_s, 'elements_total': int(mesh_s['elements'].shape[1]), 'scaling': 'strong',
+                       'active_ranks': shard_s.sh.active_world,
                        'per_rank': [{'points': int(r[2]), 'point_ms': r[0], 'assembly_ms': r[1]} for r in rk],
-                       'exchange_ms': exchange_ms(shard_s)}
+                       'exchange': exchange_report(shard_s, dt_s)}
         shard_s.sh.close()
 
-    route = (os.environ.get('FEP_P1_PATH', '') or 'node') if et == 'P1' else 'element'
-    patch_form = os.environ.get('FEP_GEN_PATH', 'patch') != 'coo'      # the library's default
-    if et != 'P1' or route == 'coo':
+    # what the library runs (FEP_ROUTE: unset = the product's default route; coo / patch = the element route's cross-check forms)
+    env_route = os.environ.get('FEP_ROUTE', '')
+    route = ('node' if not env_route else 'coo' if env_route == 'coo' else 'element') if et == 'P1' else 'element'
+    patch_form = env_route != 'coo'
+    k_names = ctx.kernel_names(0)                   # as rocprofv3 prints them (fep_ctx_kernel_names)
+    if et != 'P1' or route != 'node':
         # element route: strain + return map + K_e blocks in one kernel; patch form (default): closed CSR blocks written by the
         # same kernel, fixup_kernel for the node pairs on patch boundaries — the priced work is the pair
         k_ms = kms['element'] + (kms['csr'] if patch_form else 0.0)
         if patch_form:
-            k_name = f'element_kernel<{et}> (strain + return map + K_e in LDS + closed CSR blocks) + fixup_kernel (patch-boundary blocks)'
+            k_name = k_names + ' (strain + return map + K_e in LDS + closed CSR blocks; patch-boundary blocks)'
             others = {'element_kernel': kms['element'], 'fixup_kernel': kms['csr']}
         else:
-            k_name = f'element_kernel<{et}> (strain + return map + K_e/f_e blocks to HBM)'
+            k_name = k_names.split(' + ')[0] + ' (strain + return map + K_e/f_e blocks to HBM)'
             others = {'csr_reduce_kernel': kms['csr'], 'force_reduce_kernel': kms['force']}
         per_k = None
     else:
@@ -396,18 +459,19 @@ def run(args):
         # figure divides SURVEY 8d's bytes by the SUM of both durations (which also includes the CSR
         # numeric phase and the force gather that 8d prices separately)
         k_ms = kms['element'] + kms['csr']
-        k_name = 'p1_point_kernel + p1_node_kernel (strain + return map; tangent CSR values + force)'
-        others = {'p1_point_kernel': kms['element'], 'p1_node_kernel': kms['csr']}
+        k_name = k_names + ' (strain + return map; tangent CSR values + force)'
+        n_point, n_asm = k_names.split(' + ')
+        others = {n_point: kms['element'], n_asm: kms['csr']}
         # each kernel against its OWN minimal HBM bytes: point = elem ids 12 + ep 32
         # + coordinates/displacements 32 (16 B per node, ~2 elements per node) + s 32 + ds 72 + ind_p 1 = 181 B (the
         # materials are constant over the mesh here and are not read: 32 B less than the general case);
         # assembly = ds 48 (6 of 9 rows) + s 24 + geometry record 48 + descriptors/codes 32 + CSR values 8*nnz/n + force 16*n_n/n
         b_point = 181.0 * n_int
         b_node = (48 + 24 + 48 + 32) * n_int + 8.0 * ctx.nnz + 8.0 * ctx.n_dof
-        per_k = {'p1_point_kernel': {'bytes': b_point, 'GBps': b_point / (kms['element'] * 1e-3) / 1e9,
-                                     'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                 'p1_node_kernel': {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
-                                    'frac': b_node / (kms['csr'] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        per_k = {n_point: {'bytes': b_point, 'GBps': b_point / (kms['element'] * 1e-3) / 1e9,
+                           'frac': b_point / (kms['element'] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                 n_asm: {'bytes': b_node, 'GBps': b_node / (kms['csr'] * 1e-3) / 1e9,
+                         'frac': b_node / (kms['csr'] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     alg = ALG_BYTES[et] * n_int
     # Duration of the priced kernels per launch: the HIP events around the K TIMED steps on the launch stream, divided by K.  In
     # the default forms a step enqueues the priced kernels and nothing else (P1 node route: point + assembly kernel; patch form:
@@ -418,7 +482,7 @@ def run(args):
     k_ms_split = k_ms
     # N > 1: the launch stream also waits for the interface exchange of two passes earlier (double-buffered force vector), which
     # is not kernel time: the per-kernel event pairs stay the priced duration there.
-    if world == 1 and ((et == 'P1' and route == 'node') or (et != 'P1' and patch_form)):
+    if world == 1 and (route == 'node' or patch_form):
         k_ms = stream_ms
         timing = (f'HIP events on the launch stream around the {args.steps} timed steps / {args.steps} (the step\'s kernels back to '
                   f'back); kernels_ms: a second pass with an event pair around every kernel (sum {k_ms_split:.4f} ms)')
@@ -432,11 +496,19 @@ def run(args):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if (et == 'P1' and tj.get('elements_per_gpu', 1002528) == n_int and route == 'node' and args.field_scale == 1.0
-                        and args.state == 'bands'):
+                # the recorded counter passes must be of the kernels this run is about to price, on this workload — else null
+                same_kernels = sorted(tj.get('kernels', {})) == sorted(k_names.split(' + '))
+                if (same_kernels and tj.get('elements_per_gpu', 1002528) == n_int // NQ[et] and tj.get('element_type', 'P1') == et
+                        and args.field_scale == 1.0 and args.state == tj.get('state', 'bands')):
                     traffic = tj.get('hbm_bytes_per_launch')
                     traffic_source = ('profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
                                       '`python bench.py`, 2*FETCH + WRITE per the gfx950 correction; not measured in this run)')
+                    kf_names = ctx.kernel_names(1).split(' + ')
+                    if kf and sorted(tj.get('kf_only_kernel', {})) == sorted(kf_names):
+                        kf['traffic'] = sum(tj['kf_only_kernel'].values())
+                elif not same_kernels:
+                    print(f'[bench] profiles/traffic_latest.json is of other kernels ({sorted(tj.get("kernels", {}))}): traffic null',
+                          file=sys.stderr)
             except Exception:
                 traffic = None
         label = ' (BASELINE configs[3])' if (et, N) == ('P1', N_CELLS) else ' (BASELINE configs[4])' if (et, N) == ('P2', 1414) else ''
@@ -457,7 +529,9 @@ def run(args):
                        'nnz_per_gpu': ctx.nnz,
                        'smooth_points': n_smooth, 'apex_points': n_apex, 'field_scale': args.field_scale, 'state': args.state,
                        'route': route,
-                       'parallelism': f'element-shard x{world}, interface-force all-reduce' if world > 1 else 'single GPU'},
+                       'elements_per_gpu': n_int // NQ[et],
+                       'parallelism': (f'element-shard x{world} ({shard.sh.active_world} active), interface-force exchange: '
+                                       f'{args.exchange}') if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': k_name, 'kernel_ms': k_ms,
@@ -466,7 +540,9 @@ def run(args):
         }
         if world > 1:
             line['per_rank'] = [{'point_ms': r[0], 'assembly_ms': r[1]} for r in ranks_ms]      # first / second kernel of the step
-            line['exchange_ms'] = x_ms
+            line['exchange'] = x_rep
+            line['exchange_ms'] = x_rep['alone_ms']                   # {'allreduce': ms, 'p2p': ms}; the headline used x_rep['headline']
+            line['active_ranks'] = shard.sh.active_world               # < n_gpus: the min-elements-per-rank gate left ranks idle
             if strong_line:
                 line['strong'] = strong_line
         if kf:

@@ -18,6 +18,7 @@ c_void_pp = C.POINTER(C.c_void_p)
 # name -> (restype, argtypes); the complete export list of include/fep.h
 PROTOTYPES = {
     'fep_version': (C.c_int, []),
+    'fep_build_is_ablation': (C.c_int, []),
     'fep_strerror': (C.c_char_p, [C.c_int]),
     'fep_last_hip_error': (C.c_int, []),
     'fep_device_count': (C.c_int, [C.POINTER(C.c_int)]),
@@ -52,8 +53,10 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_assemble_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_ctx_kernel_names': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int64]),
     'fep_gather_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_scatter_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fep_iface_sum_f64': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_transform_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_transform_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'fep_solver_create': (C.c_int, [c_void_pp, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -27,20 +27,27 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Compile the shared library if it is missing or older than its sources."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-o', LIB + '.tmp'] + SOURCES
+LIB_ABLATION = os.path.join(CSRC, 'libfep_hip_abl.so')
+
+
+def build(force=False, verbose=False, ablation=False):
+    """Compile the shared library if it is missing or older than its sources.
+    ablation=True: the measurement build (-DFEP_ABLATION: variant switches by environment variable, phase clocks) as
+    csrc/libfep_hip_abl.so — never loaded unless FEP_LIB_PATH names it (tools/ only)."""
+    lib = LIB_ABLATION if ablation else LIB
+    if not force and not ablation and not needs_build():
+        return lib
+    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared'] + (['-DFEP_ABLATION'] if ablation else []) + \
+          ['-o', lib + '.tmp'] + SOURCES
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError('hipcc failed:\n' + res.stdout)
-    os.replace(LIB + '.tmp', LIB)
-    return LIB
+    os.replace(lib + '.tmp', lib)
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, ablation='--ablation' in sys.argv))

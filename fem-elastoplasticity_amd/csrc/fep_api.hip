@@ -16,8 +16,26 @@
 
 using namespace fep;
 
+// workgroup shape of the 15-node element's patch form (decided by measurement, profiles/r04_ablation.md)
+#ifndef FEP_P4_TPB
+#define FEP_P4_TPB 512
+#define FEP_P4_JS 2
+#endif
+
 thread_local int fep_g_last_hip = 0;
 #define g_last_hip fep_g_last_hip
+
+// The switches of the PRODUCT library (read once): everything else goes through fep_tune() and exists in -DFEP_ABLATION
+// builds only (fep_common.h).
+//   FEP_ROUTE=coo | patch   the element route in its COO form (every K_e block through HBM, csr_reduce_kernel) / its patch
+//                           form for EVERY element type, P1 included: the independent cross-checks of the parity tests
+//                           (unset: P1 takes its node route, the other types the patch form)
+//   FEP_VALIDATE_PLAN=1     replay the gather plan against the symbolic phase at context creation (tests)
+//   FEP_VERBOSE=1           plan statistics on stderr
+static const char* env_once(const char* name) { const char* v = std::getenv(name); return (v && *v) ? v : nullptr; }
+static bool route_is(const char* v) { static const char* r = env_once("FEP_ROUTE"); return r && std::strcmp(r, v) == 0; }
+static bool validate_plans() { static const bool on = env_once("FEP_VALIDATE_PLAN") != nullptr; return on; }
+static bool verbose_on() { static const bool on = env_once("FEP_VERBOSE") != nullptr; return on; }
 
 struct fep_ctx {
     int device = 0;
@@ -32,7 +50,7 @@ struct fep_ctx {
     bool kc_aos = false;                                // K_e half-blocks: all blocks of an element adjacent (AoS) or block-major (SoA)
     // patch route of the element kernel (default; FEP_GEN_PATH=coo keeps the K_e round trip): fep_host.h, PatchPlan
     bool patch = false;
-    int patch_eb = 0, patch_dbg = 0, patch_tpb = 256;   // FEP_PATCH_TPB=512 (P2): patches of twice the elements, 512-thread workgroups
+    int patch_eb = 0, patch_dbg = 0, patch_tpb = 256, patch_js = 1;   // workgroup shape of the patch form (ElemCfg)
     int lds_pad = 0;                                    // FEP_ELEM_LDS_PAD: extra LDS bytes per workgroup of element_kernel (occupancy experiments)
     int64_t n_open = 0, n_fopen = 0;
     int32_t *pt_desc = nullptr, *pt_plist = nullptr, *pt_pel = nullptr, *pt_pnodes = nullptr;
@@ -41,6 +59,10 @@ struct fep_ctx {
     uint4 *pt_fix = nullptr, *pt_ffix = nullptr;
     uint2* pt_fixT = nullptr;
     int64_t n_patch = 0;
+    int patch_slots[2] = {0, 0};                        // resident workgroups of the patch kernel (assembly-only / from U), asked once
+#ifdef FEP_ABLATION
+    unsigned long long* phase_clk = nullptr;            // FEP_PHASE_CLK=1: phase stamps of the last element_kernel launch (reported at destroy)
+#endif
     double *Pc = nullptr, *Pf = nullptr;                // partial blocks / forces of the open items (scratch, rewritten by every step)
     bool elem_geo = true;                               // element_kernel: geometry from coordinates instead of the dphi arrays
     MatU matu{};                                        // homogeneous-material fast path (arrays not read)
@@ -120,6 +142,13 @@ static inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)((n
 
 // ---------------------------------------------------------------------------------------
 extern "C" int fep_version(void) { return 1; }
+extern "C" int fep_build_is_ablation(void) {
+#ifdef FEP_ABLATION
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" const char* fep_strerror(int code) {
     switch (code) {
@@ -212,7 +241,8 @@ static int rm_scratch(int device, hipStream_t st, size_t n_blocks, uint2** out) 
     auto& b = bufs[{device, (void*)st}];
     if (b.second < n_blocks) {
         FEP_TRY(scratch_alloc_allowed(st));
-        if (b.first) { HIP_TRY(hipFree(b.first)); b = {nullptr, 0}; }
+        static auto& retired = *new std::vector<uint2*>();
+        if (b.first) { retired.push_back(b.first); b = {nullptr, 0}; }
         const size_t cap = n_blocks + n_blocks / 4 + 64;
         HIP_TRY(hipMalloc((void**)&b.first, cap * sizeof(uint2)));
         b.second = cap;
@@ -297,7 +327,7 @@ static int return_map_host_impl(int device_id, int64_t n_int,
     if (ds_h) FEP_TRY(E->buffer(7, 9 * nb, &ds));
     if (ind_p_h) FEP_TRY(E->buffer(8, n_int, &ip));
     FEP_TRY(E->buffer(9, 2 * sizeof(int64_t), &cnt));
-    static const bool timing = std::getenv("FEP_TIME_HOST") != nullptr;
+    static const bool timing = fep_tune("FEP_TIME_HOST") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     FEP_TRY(E->h2d(e, e_h, (size_t)span * sizeof(double)));
     if (ep_prev_h) FEP_TRY(E->h2d(ep, ep_prev_h, (size_t)(4 * nb)));
@@ -362,6 +392,26 @@ static int launch_geometry(fep_ctx* c) {
 extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (!c) return FEP_OK;
     if (fep_set_device(c->device) == FEP_OK) {
+#ifdef FEP_ABLATION
+        if (c->phase_clk && c->n_patch > 0) {            // mean shader clocks per phase of the LAST element_kernel launch
+            std::vector<unsigned long long> h((size_t)(8 * c->n_patch));
+            if (hipDeviceSynchronize() == hipSuccess &&
+                hipMemcpy(h.data(), c->phase_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double acc[6] = {0, 0, 0, 0, 0, 0};
+                unsigned long long lo = ~0ull, hi = 0;
+                for (int64_t p = 0; p < c->n_patch; ++p) {
+                    const unsigned long long* s = h.data() + 8 * p;
+                    for (int k = 0; k < 6; ++k) acc[k] += (double)(s[k + 1] - s[k]);
+                    lo = std::min(lo, s[0]); hi = std::max(hi, s[6]);
+                }
+                std::fprintf(stderr, "[fep] phase clocks, mean per workgroup of %lld (stage, phase1, phase2, wait, image, phase3): "
+                             "%.0f %.0f %.0f %.0f %.0f %.0f  sum %.0f; first start -> last end %llu\n", (long long)c->n_patch,
+                             acc[0] / c->n_patch, acc[1] / c->n_patch, acc[2] / c->n_patch, acc[3] / c->n_patch, acc[4] / c->n_patch,
+                             acc[5] / c->n_patch, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / c->n_patch, hi - lo);
+            }
+            (void)hipFree(c->phase_clk);
+        }
+#endif
         void* ptrs[] = {c->elem, c->coords, c->dh1, c->dh2, c->wf, c->dphi1, c->dphi2, c->weight, c->det, c->shear, c->bulk,
                         c->eta, c->c, c->segptr, c->perm, c->iptr, c->ilist, c->meta, c->Kc, c->fe, c->geo, c->perm2,
                         c->ncol, c->s_int, c->ds_int, c->blk_counts, c->wg_eptr, c->wg_elist, c->wg_rng, c->perm_l, c->xy, c->pk, c->tdesc, c->tstart,
@@ -399,6 +449,16 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
     }
     if (r != FEP_OK) { if (c) fep_ctx_destroy(c); *ctx_out = nullptr; }
     return r;
+}
+
+// The element kernel's per-type choices (measured; the notes are at their use in ctx_create_impl)
+static constexpr bool elem_geo_default(int elem_type, bool patch_form) {
+    return elem_type == FEP_Q1 || elem_type == FEP_Q2 || (elem_type == FEP_P2 && patch_form);
+}
+static void patch_shape_default(int elem_type, bool patch_form, int& tpb, int& js) {
+    tpb = 256; js = 1;
+    if (patch_form && elem_type == FEP_P2) tpb = 512;
+    if (patch_form && elem_type == FEP_P4) { tpb = FEP_P4_TPB; js = FEP_P4_JS; }
 }
 
 static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int elem_type, int64_t n_e, int64_t n_n,
@@ -447,35 +507,47 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     // COO route: tiles of whole nodes with at most kBlock node-pair blocks (csr_reduce_kernel's work units)
     std::vector<int32_t> tstart_all;
     CK(fep_host::row_tiles(S, n_n, kBlock, tstart_all));
-    {   // P1 runs the node-centric fast path unless FEP_P1_PATH=coo asks for the generic COO route
-        const char* pth = std::getenv("FEP_P1_PATH");
-        c->p1_node = elem_type == FEP_P1 && !(pth && std::strcmp(pth, "coo") == 0);
-    }
+    // P1 runs the node-centric fast path unless FEP_ROUTE asks for the element route (coo | patch)
+    c->p1_node = elem_type == FEP_P1 && !route_is("coo") && !route_is("patch");
     if (c->p1_node) {
         // gather plan of the node route (host, fep_host.h): tiles, staged element / node lists, codes, descriptors
-        const char* pth = std::getenv("FEP_P1_PATH");
-        auto is = [&](const char* v) { return pth && std::strcmp(pth, v) == 0; };
         fep_host::P1Options opt;
         opt.tile = c->tile;
-        opt.allow_lds = !is("node_direct");
-        opt.allow_rng = !is("node_list");
-        opt.allow_pk = !is("node_unpacked");
-        opt.allow_fused = !is("node2k");
-        if (const char* sg = std::getenv("FEP_P1_SEGS")) opt.max_segs = std::max(1, std::min(std::atoi(sg), fep_host::kSegMax));
+#ifdef FEP_ABLATION
+        {   // FEP_P1_PATH=node_direct | node_list | node_unpacked | node2k: plans without one of the default's ingredients
+            const char* pth = fep_tune("FEP_P1_PATH");
+            auto is = [&](const char* v) { return pth && std::strcmp(pth, v) == 0; };
+            opt.allow_lds = !is("node_direct");
+            opt.allow_rng = !is("node_list");
+            opt.allow_pk = !is("node_unpacked");
+            opt.allow_fused = !is("node2k");
+            if (const char* sg = fep_tune("FEP_P1_SEGS")) opt.max_segs = std::max(1, std::min(std::atoi(sg), fep_host::kSegMax));
+        }
+#endif
         fep_host::P1Plan P;
         CK(fep_host::build_p1_plan(S, n_e, n_n, elements_h, opt, P));
-        if (r == FEP_OK && std::getenv("FEP_VALIDATE_PLAN")) {
+        if (r == FEP_OK && validate_plans()) {
             const int bad = fep_host::validate_p1_plan(P, S, n_e, n_n, elements_h);
             if (bad) { std::fprintf(stderr, "[fep] P1 plan fails check %d\n", bad); r = FEP_EINVAL; }
         }
-        if (r == FEP_OK) {
+#ifndef FEP_ABLATION
+        // A mesh whose tiles do not fit the LDS-staged form or whose descriptor fields do not pack (node degree >= 2^12, ...)
+        // takes the element route like every other element type: the product keeps ONE node route.
+        if (r == FEP_OK && !(P.lds && P.pk)) {
+            c->p1_node = false;
+            if (verbose_on()) std::fprintf(stderr, "[fep] P1 plan without the LDS-staged packed form (lds %d pk %d): element route\n", (int)P.lds, (int)P.pk);
+        }
+#endif
+        if (r == FEP_OK && c->p1_node) {
             c->n_wg_p1 = (int)P.n_wg; c->p1_segs = P.n_segs;
             c->p1_lds = P.lds; c->lds_L = P.L; c->lds_C = P.C; c->p1_rng = P.rng; c->p1_pk = P.pk;
             c->p1_fused = P.fused; c->p1_fused_rng = P.fused_rng; c->lds_NL = P.NL;
-            if (const char* am = std::getenv("FEP_P1_ASM")) c->asm_from_nodes = std::strcmp(am, "nodes") == 0;
-            if (const char* dm = std::getenv("FEP_P1_DMA")) c->p1_dma = std::strcmp(dm, "0") != 0;
-            if (const char* fm = std::getenv("FEP_P1_FUSED"))
+#ifdef FEP_ABLATION
+            if (const char* am = fep_tune("FEP_P1_ASM")) c->asm_from_nodes = std::strcmp(am, "nodes") == 0;
+            if (const char* dm = fep_tune("FEP_P1_DMA")) c->p1_dma = std::strcmp(dm, "0") != 0;
+            if (const char* fm = fep_tune("FEP_P1_FUSED"))
                 c->fused_mode = std::strcmp(fm, "off") == 0 ? 0 : std::strcmp(fm, "kf") == 0 ? 1 : 2;
+#endif
             CK(upload(&c->perm2, P.perm2.data(), (int64_t)P.perm2.size()));
             CK(upload(&c->ncol, S.ncol.data(), (int64_t)S.ncol.size()));
             CK(upload(&c->tdesc, (const int4*)P.tdesc.data(), (int64_t)P.tdesc.size() / 4));
@@ -492,24 +564,24 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 CK(dmalloc(&c->slot_counts, 256 * 16));
                 if (r == FEP_OK && hipMemset(c->slot_counts, 0, 256 * 16 * sizeof(unsigned long long)) != hipSuccess) r = FEP_EHIP;
             }
-            static const bool verbose = std::getenv("FEP_VERBOSE") != nullptr;
-            if (verbose)
+            if (verbose_on())
                 std::fprintf(stderr, "[fep] P1 plan: %lld tiles of <= %d blocks in <= %d segment(s), staged elements %lld "
                              "(%.2f per element, <= %d per tile), staged nodes <= %d, codes <= %d; lds %d rng %d pk %d fused %d/%d\n",
                              (long long)P.n_wg, P.tile, P.n_segs, (long long)P.staged_total, (double)P.staged_total / (double)n_e,
                              P.L, P.NL, P.C, (int)P.lds, (int)P.rng, (int)P.pk, (int)P.fused, (int)P.fused_rng);
         }
-        CK(dmalloc(&c->geo, 6 * n_e));
-        {
+        if (c->p1_node) {
+            CK(dmalloc(&c->geo, 6 * n_e));
             for (int a = 0; a < 3; ++a) { c->p1tab.h1[a] = dhatp1_h[a]; c->p1tab.h2[a] = dhatp2_h[a]; }
             c->p1tab.wf = wf_h[0];
+            c->n_count_blocks = (int)grid_for(n_e, kBlock);
         }
-        c->n_count_blocks = (int)grid_for(n_e, kBlock);
-    } else {
-        // P2 / Q1 / Q2: the COO route is the default; FEP_GEN_PATH=node selects the node route (measured on
-        // MI355X, 1 M elements: Q1 0.276 vs 0.286 ms, P2 1.80 vs 1.30 ms, Q2 0.41 vs 0.34 ms per step — its LDS
-        // gather costs n_q times the P1 one)
-        const char* gp = std::getenv("FEP_GEN_PATH");
+    }
+#ifdef FEP_ABLATION
+    else {
+        // FEP_GEN_PATH=node: node route for P2 / Q1 / Q2 (point_kernel + node_lds_kernel; measured on MI355X, 1 M elements:
+        // Q1 0.276 vs 0.286 ms, P2 1.80 vs 1.30 ms, Q2 0.41 vs 0.34 ms per step — its LDS gather costs n_q times the P1 one)
+        const char* gp = fep_tune("FEP_GEN_PATH");
         const bool want_gn = (elem_type == FEP_P2 || elem_type == FEP_Q1 || elem_type == FEP_Q2) &&
                              gp && std::strcmp(gp, "node") == 0 && r == FEP_OK;
         if (want_gn) {
@@ -524,78 +596,99 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
             }
         }
     }
+#endif
+    // element route: the patch form (no K_e round trip through HBM; default) or the COO form (FEP_ROUTE=coo).
+    // Same session, 0.25-4 M elements (profiles/r03_ablation.md, r03_elem_bench.log): P2 -17 % (K,F-only -19 %, BASELINE
+    // configs[4] -14 %), Q2 -14 %, Q1 -13 %, P4 -21 % against the COO form
+    const bool coo_form = route_is("coo");
+    const bool want_patch = !c->p1_node && !c->gn && !coo_form;
     {   // interleaved (x, y) per node: the kernels recompute dphi / weight from the coordinates
         std::vector<double> xy(2 * (size_t)n_n);
         for (int64_t n = 0; n < n_n; ++n) { xy[2 * n] = coords_h[n]; xy[2 * n + 1] = coords_h[n_n + n]; }
         CK(upload(&c->xy, xy.data(), (int64_t)xy.size()));
-        const char* ge = std::getenv("FEP_ELEM_GEO");
-        // measured on MI355X (1 M elements, element kernel alone): recomputed geometry wins for Q1 (0.204 vs 0.218 ms) and
-        // Q2 (0.344 vs 0.391 ms with 24 instead of 28 elements per workgroup, so that three workgroups still fit a CU) and
-        // loses for P2 (0.50 vs 0.47 ms at 28 / 32 elements per workgroup)
-        // round 3, patch form of the element route: recomputed geometry wins for P2 as well (same session, 1 M elements:
-        // 0.754 vs 0.783 ms on a fast box, 0.888 vs 0.936 on a slow one); the COO form keeps the streamed dphi arrays for P2
-        const char* gpth = std::getenv("FEP_GEN_PATH");
-        const bool coo_form = gpth && std::strcmp(gpth, "coo") == 0;
-        c->elem_geo = ge ? std::strcmp(ge, "0") != 0 : (elem_type == FEP_Q1 || elem_type == FEP_Q2 || (elem_type == FEP_P2 && !coo_form));
+        // geometry of the element kernel from the coordinates (GEO) or from the streamed dphi arrays, fixed per type and form
+        // (elem_geo_default): measured on MI355X (1 M elements, element kernel alone): recomputed geometry wins for Q1 (0.204 vs
+        // 0.218 ms) and Q2 (0.344 vs 0.391 ms with 24 instead of 28 elements per workgroup, so that three workgroups still fit a
+        // CU) and loses for P2 in the COO form (0.50 vs 0.47 ms at 28 / 32 elements per workgroup); round 3, patch form:
+        // recomputed geometry wins for P2 as well (same session, 1 M elements: 0.754 vs 0.783 ms on a fast box, 0.888 vs 0.936
+        // on a slow one)
+        c->elem_geo = elem_geo_default(elem_type, want_patch);
+#ifdef FEP_ABLATION
+        if (const char* ge = fep_tune("FEP_ELEM_GEO")) c->elem_geo = std::strcmp(ge, "0") != 0;
+        if (const char* lp = fep_tune("FEP_ELEM_LDS_PAD")) c->lds_pad = std::max(0, std::atoi(lp));
+#endif
     }
     // node -> incident (element, local node) lists: force gather of the COO route and fep_transform_*
     CK(upload(&c->iptr, S.iptr.data(), (int64_t)S.iptr.size()));
     CK(upload(&c->ilist, S.ilist.data(), (int64_t)S.ilist.size()));
-    if (const char* lp = std::getenv("FEP_ELEM_LDS_PAD")) c->lds_pad = std::max(0, std::atoi(lp));
     int elem_eb = 1;
-    // element route: the patch form (no K_e round trip through HBM; default) or the COO form (FEP_GEN_PATH=patch | coo).
-    // Same session, 0.25-4 M elements (profiles/r03_ablation.md, r03_elem_bench.log): P2 -17 % (K,F-only -19 %, BASELINE
-    // configs[4] -14 %), Q2 -14 %, Q1 -13 %, P4 -21 % against the COO form
-    const char* gen_path = std::getenv("FEP_GEN_PATH");
-    const bool want_patch = !c->p1_node && !c->gn && !(gen_path && std::strcmp(gen_path, "coo") == 0);
-    // P2 patches: 56 elements on 512 threads (two workgroups of eight waves per CU instead of four of four: the same waves,
-    // 2.0 instead of 3.2 partials per element with four runs, fix-up kernel -35 %, element kernel +3-12 %): three boxes, same
-    // session each: 1 M elements 0.653 / 0.681 / 0.724 against 0.700 / 0.713 / 0.716 ms, BASELINE configs[4] 2.61 / 2.89 / 2.89
-    // against 2.86 / 3.09 / 3.00, K,F-only 0.613 against 0.653; FEP_PATCH_TPB=256|512 forces one
-    const char* tpb_env = std::getenv("FEP_PATCH_TPB");
-    // (Q2 with 40 elements on 512 threads, 3.5 instead of 5.8 partials per element: 0.76-0.80 against 0.62 ms, not kept)
-    const bool p2_patch = want_patch && elem_type == FEP_P2;
-    c->patch_tpb = !p2_patch ? 256 : tpb_env ? (std::atoi(tpb_env) == 512 ? 512 : 256) : 512;
-    const auto elements_per_workgroup = [&]() {
+    // Workgroup shape of the patch form (threads; lanes per (element, node) pair in phase 2: ElemCfg's JS), fixed per type:
+    //   P2  512 / 1: 56 elements on 512 threads (two workgroups of eight waves per CU instead of four of four: the same waves,
+    //       2.0 instead of 3.2 partials per element with four runs, fix-up kernel -35 %, element kernel +3-12 %): three boxes,
+    //       same session each: 1 M elements 0.653 / 0.681 / 0.724 against 0.700 / 0.713 / 0.716 ms, BASELINE configs[4] 2.61 /
+    //       2.89 / 2.89 against 2.86 / 3.09 / 3.00, K,F-only 0.613 against 0.653
+    //   Q2  256 / 1 (40 elements on 512 threads, 3.5 instead of 5.8 partials per element: 0.76-0.80 against 0.62 ms; 24 elements
+    //       on 384 threads with JS = 2: 0.82-0.83 against 0.62, profiles/r04_ablation.md)
+    patch_shape_default(elem_type, want_patch, c->patch_tpb, c->patch_js);
+    bool shape_forced = false;
+#ifdef FEP_ABLATION
+    if (const char* tpb_env = want_patch ? fep_tune("FEP_PATCH_TPB") : nullptr) {
+        c->patch_tpb = std::atoi(tpb_env);
+        const char* js_env = fep_tune("FEP_PATCH_JS");
+        c->patch_js = js_env ? std::atoi(js_env) : 1;
+        shape_forced = true;
+    }
+#endif
+    const auto elements_per_workgroup = [&]() -> int {
         const bool g = c->elem_geo;
+        const int tpb = c->patch_tpb, js = c->patch_js;
+#define EBOF(NP, NQ, TPB, JS) if (tpb == TPB && js == JS) return g ? ElemCfg<NP, NQ, true, TPB, JS>::EB : ElemCfg<NP, NQ, false, TPB, JS>::EB
         switch (elem_type) {
-            case FEP_P1: return g ? ElemCfg<3, 1, true>::EB : ElemCfg<3, 1, false>::EB;
-            case FEP_P2: return c->patch_tpb == 512 ? (g ? ElemCfg<6, 7, true, 512>::EB : ElemCfg<6, 7, false, 512>::EB)
-                                                    : (g ? ElemCfg<6, 7, true>::EB : ElemCfg<6, 7, false>::EB);
-            case FEP_Q1: return g ? ElemCfg<4, 4, true>::EB : ElemCfg<4, 4, false>::EB;
-            case FEP_Q2: return g ? ElemCfg<8, 9, true>::EB : ElemCfg<8, 9, false>::EB;
-            case FEP_P4: return g ? ElemCfg<15, 12, true>::EB : ElemCfg<15, 12, false>::EB;
+            case FEP_P1: EBOF(3, 1, 256, 1); break;
+            case FEP_P2: EBOF(6, 7, 256, 1); EBOF(6, 7, 512, 1); break;
+            case FEP_Q1: EBOF(4, 4, 256, 1); break;
+            case FEP_Q2: EBOF(8, 9, 256, 1);
+#ifdef FEP_ABLATION
+                EBOF(8, 9, 384, 2); EBOF(8, 9, 512, 1);
+#endif
+                break;
+            case FEP_P4: EBOF(15, 12, 256, 1); EBOF(15, 12, 512, 2); break;
         }
-        return 1;
+#undef EBOF
+        return 0;                                        // no such instantiation
     };
     elem_eb = elements_per_workgroup();
+    if (elem_eb == 0) return FEP_EINVAL;
     if (!c->p1_node && !c->gn && r == FEP_OK) {
         if (want_patch) {
             fep_host::PatchPlan P;
             fep_host::PatchOptions popt;
-            if (const char* po = std::getenv("FEP_PATCH_ORDER"))
+#ifdef FEP_ABLATION
+            if (const char* po = fep_tune("FEP_PATCH_ORDER"))
                 popt.order = std::strcmp(po, "consecutive") == 0 ? 0 : std::strcmp(po, "hilbert") == 0 ? 1 : 2;
+#endif
             // Q1 (64 elements per patch): 4 runs of 16 measured 6 % faster than 2 of 32; P2 with 56 elements: 4 runs of 14
             // (1.96 partials per element) 1-3 % faster than 2 of 28 (2.86); with 28 elements 2 runs of 14 (4 of 7: +7 %)
             popt.runs = (elem_type == FEP_Q1 || c->patch_tpb == 512) ? 4 : 2;
-            if (const char* pr = std::getenv("FEP_PATCH_RUNS")) popt.runs = std::max(1, std::atoi(pr));
-            // runs starting on 128-byte boundaries of the point arrays (16 / gcd(16, n_q) elements) measured no faster and
-            // cost a third more partials (the aligned starts leave short leftovers): off unless asked for
-            if (const char* pa = std::getenv("FEP_PATCH_ALIGN")) popt.align = std::max(1, std::atoi(pa));
+            // (runs starting on 128-byte boundaries of the point arrays — 16 / gcd(16, n_q) elements — measured no faster and
+            // cost a third more partials: the aligned starts leave short leftovers)
+#ifdef FEP_ABLATION
+            if (const char* pr = fep_tune("FEP_PATCH_RUNS")) popt.runs = std::max(1, std::atoi(pr));
+            if (const char* pa = fep_tune("FEP_PATCH_ALIGN")) popt.align = std::max(1, std::atoi(pa));
+#endif
             CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
-            if (r == FEP_OK && !P.ok && c->patch_tpb == 512 && !tpb_env) {     // the big patches cannot be built: the small ones
+            if (r == FEP_OK && !P.ok && c->patch_tpb == 512 && c->patch_js == 1 && !shape_forced) {     // the big patches cannot be built: the small ones
                 c->patch_tpb = 256;                                            // (a forced size is never changed silently)
                 elem_eb = elements_per_workgroup();
-                if (!std::getenv("FEP_PATCH_RUNS")) popt.runs = 2;
+                if (!fep_tune("FEP_PATCH_RUNS")) popt.runs = 2;
                 CK(fep_host::build_patch_plan(S, n_p, n_e, n_n, elements_h, coords_h, elem_eb, popt, P));
             }
-            if (r == FEP_OK && P.ok && std::getenv("FEP_VALIDATE_PLAN")) {
+            if (r == FEP_OK && P.ok && validate_plans()) {
                 const int bad = fep_host::validate_patch_plan(P, S, n_p, n_e, n_n, elements_h);
                 if (bad) { std::fprintf(stderr, "[fep] patch plan fails check %d\n", bad); r = FEP_EINVAL; }
             }
             if (r == FEP_OK && P.ok) {
                 c->patch = true; c->patch_eb = P.eb; c->n_open = P.n_open; c->n_fopen = P.n_fopen; c->n_patch = P.n_patch;
-                if (const char* db = std::getenv("FEP_PATCH_DBG")) c->patch_dbg = std::atoi(db);
                 CK(upload(&c->pt_desc, P.pdesc.data(), (int64_t)P.pdesc.size()));
                 CK(upload(&c->pt_pel, P.pel.data(), (int64_t)P.pel.size()));
                 CK(upload(&c->pt_pnodes, P.pnodes.data(), (int64_t)P.pnodes.size()));
@@ -607,10 +700,15 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 CK(upload(&c->pt_fixT, (const uint2*)P.fixT.data(), (int64_t)P.fixT.size()));
                 CK(upload(&c->pt_ffix, (const uint4*)P.ffix.data(), (int64_t)P.ffix.size()));
                 CK(upload(&c->pt_plist, P.plist.data(), (int64_t)P.plist.size()));
+#ifdef FEP_ABLATION
+                if (fep_tune("FEP_PHASE_CLK")) {
+                    CK(dmalloc(&c->phase_clk, 8 * P.n_patch));
+                    if (r == FEP_OK) (void)hipMemset(c->phase_clk, 0, (size_t)(8 * P.n_patch) * sizeof(unsigned long long));
+                }
+#endif
                 CK(dmalloc(&c->Pc, 4 * P.n_part));
                 CK(dmalloc(&c->Pf, 2 * P.n_fpart));
-                static const bool verbose = std::getenv("FEP_VERBOSE") != nullptr;
-                if (verbose)
+                if (verbose_on())
                     std::fprintf(stderr, "[fep] patch plan: %lld patches of <= %d elements, %zu items (<= %d per patch), %lld open blocks of %lld, "
                                  "%lld partials (%.2f per element), %lld open nodes\n", (long long)P.n_patch, P.eb, P.items.size(), P.max_items,
                                  (long long)P.n_open, (long long)c->n_blk, (long long)P.n_part, (double)P.n_part / (double)n_e,
@@ -619,7 +717,8 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         }
         c->n_count_blocks = c->patch ? (int)c->n_patch : (int)grid_for(n_e, elem_eb);
     }
-    if (!c->patch && c->patch_tpb != 256) r = r == FEP_OK ? FEP_ESTATE : r;        // (a forced 512-thread plan that could not be built)
+    if (!c->patch && shape_forced && c->patch_tpb != 256) r = r == FEP_OK ? FEP_ESTATE : r;        // (a forced plan that could not be built)
+    if (!c->patch) { c->patch_tpb = 256; c->patch_js = 1; }
     if (!c->patch) {
         CK(upload(&c->segptr, S.segptr.data(), (int64_t)S.segptr.size()));
         CK(upload(&c->meta, S.meta.data(), (int64_t)S.meta.size()));
@@ -628,8 +727,10 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         // measured at ~1 M points per type (tools/elem_bench.py): the element-major layout pays for the 15-node element only
         // (P4: step 1.47 -> 1.35 ms; P2 0.96 -> 1.06, Q2 0.82 -> 0.94, Q1 0.22 -> 0.26: their stores lose coalescing)
         c->kc_aos = elem_type == FEP_P4;
-        if (const char* kl = std::getenv("FEP_KC_LAYOUT")) c->kc_aos = std::strcmp(kl, "aos") == 0;
-        if (const char* cg = std::getenv("FEP_CSR_GATHERS")) c->csr_gathers = std::atoi(cg);
+#ifdef FEP_ABLATION
+        if (const char* kl = fep_tune("FEP_KC_LAYOUT")) c->kc_aos = std::strcmp(kl, "aos") == 0;
+        if (const char* cg = fep_tune("FEP_CSR_GATHERS")) c->csr_gathers = std::atoi(cg);
+#endif
         if ((int64_t)sym_block_count(n_p) * n_e >= (int64_t)1 << 30) r = FEP_ERANGE;     // 2 * position fits int32
         {   // element_kernel stores half of the symmetric K_e: re-address the contributions (block, transposed)
             std::vector<int32_t> perm_sym(S.perm.size());
@@ -646,7 +747,7 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
             CK(upload(&c->perm, perm_sym.data(), (int64_t)perm_sym.size()));
             // one 8-byte descriptor per block, if its fields fit (count < 256, degree and slot < 4096)
             std::vector<uint2> pkc((size_t)c->n_blk);
-            bool fits = std::getenv("FEP_CSR_UNPACKED") == nullptr;
+            bool fits = fep_tune("FEP_CSR_UNPACKED") == nullptr;
             for (int64_t b = 0; b < c->n_blk && fits; ++b) {
                 const uint32_t len = (uint32_t)(S.segptr[b + 1] - S.segptr[b]), deg = S.meta[b] >> 16, slot = S.meta[b] & 0x7fffu;
                 fits = len < 256 && deg < 4096 && slot < 4096;
@@ -682,6 +783,32 @@ extern "C" int fep_ctx_sizes(const fep_ctx* c, int64_t sizes[8]) {
     if (!c || !sizes) return FEP_EINVAL;
     sizes[0] = c->n_e; sizes[1] = c->n_n; sizes[2] = c->n_p; sizes[3] = c->n_q;
     sizes[4] = c->n_int; sizes[5] = c->n_dof; sizes[6] = c->nnz; sizes[7] = c->n_blk;
+    return FEP_OK;
+}
+
+// The kernels of a step, named as rocprofv3 prints them (bench.py labels its roofline with these and checks them against the
+// kernel names of the recorded counter passes)
+extern "C" int fep_ctx_kernel_names(const fep_ctx* c, int which, char* buf, int64_t cap) {
+    if (!c || !buf || cap <= 0 || (which != 0 && which != 1)) return FEP_EINVAL;
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    char tmp[256];
+    if (c->p1_node && c->p1_lds) {
+        if (which == 1 && c->p1_fused && c->fused_mode >= 1)
+            std::snprintf(tmp, sizeof tmp, "p1_fused_kernel<false, 256, %s, 1, 1, false, %s>", b(c->p1_fused_rng), b(c->p1_dma));
+        else
+            std::snprintf(tmp, sizeof tmp, "p1_point_kernel + p1_node_lds_kernel<256, %s, 1, %s>", b(c->p1_rng), b(c->p1_pk));
+    } else if (c->p1_node) {
+        std::snprintf(tmp, sizeof tmp, "p1_point_kernel + p1_node_kernel");
+    } else if (c->gn) {
+        std::snprintf(tmp, sizeof tmp, "point_kernel<%d, %d> + node_lds_kernel<%d, %d, %d>", c->n_p, c->n_q, c->n_p, c->n_q, c->gn_tile);
+    } else if (c->patch) {
+        std::snprintf(tmp, sizeof tmp, "element_kernel<%d, %d, true, %s, true, %d, %d> + fixup_kernel", c->n_p, c->n_q, b(c->elem_geo),
+                      c->patch_tpb, c->patch_js);
+    } else {
+        std::snprintf(tmp, sizeof tmp, "element_kernel<%d, %d, true, %s, false, 256, 1> + %s", c->n_p, c->n_q, b(c->elem_geo),
+                      c->pkc ? "csr_reduce_pk_kernel" : "csr_reduce_kernel<4>");
+    }
+    std::snprintf(buf, (size_t)cap, "%s", tmp);
     return FEP_OK;
 }
 
@@ -722,7 +849,7 @@ extern "C" int fep_ctx_set_materials_host(fep_ctx* c, const double* shear_h, con
         if (!c->s_int) FEP_TRY(dmalloc(&c->s_int, 4 * c->n_int));
     }
     // every parameter constant over the mesh (the reference's demos): the kernels skip the four arrays
-    bool uni = std::getenv("FEP_NO_UNIFORM") == nullptr;
+    bool uni = fep_tune("FEP_NO_UNIFORM") == nullptr;
     for (int64_t k = 1; uni && k < c->n_int; ++k)
         uni = shear_h[k] == shear_h[0] && bulk_h[k] == bulk_h[0] && eta_h[k] == eta_h[0] && c_h[k] == c_h[0];
     c->matu = MatU{shear_h[0], bulk_h[0], eta_h[0], c_h[0], uni ? 1 : 0};
@@ -756,31 +883,67 @@ static int prof_mark(fep_ctx* c, hipStream_t st) {
     return FEP_OK;
 }
 
+// workgroups of `kernel` the whole chip keeps resident at once (CUs x occupancy): the grid of a persistent kernel
+static int resident_workgroups(const void* kernel, int tpb, size_t dyn_lds, int device, int* out) {
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, tpb, dyn_lds));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    *out = std::max(1, per_cu) * std::max(1, cus);
+    return FEP_OK;
+}
+
 template <int NP, int NQ, bool FROM_U>
 static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept,
                           double* eout, double* s, double* ds, uint8_t* indp, uint2* blk_counts,
                           double* Kc, double* fe) {
     // patch route: Kc / fe carry the caller's CSR values / force (phase 3 writes them, fixup_kernel the open rest)
     const PatchArgs pa{c->pt_desc, c->pt_pel, c->pt_pnodes, c->pt_items, c->pt_codes, c->pt_fitems, c->pt_fcodes, c->Pc, c->Pf,
-                       c->patch ? Kc : nullptr, c->patch ? fe : nullptr, c->patch_dbg};
-#define ELEM_LAUNCH(GEO, PATCH) ELEM_LAUNCH_T(GEO, PATCH, kBlock)
-#define ELEM_LAUNCH_T(GEO, PATCH, TPB)                                                                                   \
+                       c->patch ? Kc : nullptr, c->patch ? fe : nullptr, c->n_patch
+#ifdef FEP_ABLATION
+                       , c->phase_clk
+#endif
+    };
+    (void)pa;
+#define ELEM_LAUNCH_T(GEO, PATCH, TPB, JS)                                                                               \
     do {                                                                                                                 \
-        if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO, TPB>::EB) return FEP_ESTATE;                        \
-        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB>),                                           \
-                           dim3(PATCH ? (unsigned)c->n_patch : grid_for(c->n_e, ElemCfg<NP, NQ, GEO, TPB>::EB)),           \
+        if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO, TPB, JS>::EB) return FEP_ESTATE;                    \
+        /* patch form: ONE wave of resident workgroups, each walking patches g, g + G, ... (persistent, software-pipelined) */ \
+        unsigned grid = grid_for(c->n_e, ElemCfg<NP, NQ, GEO, TPB, JS>::EB);                                            \
+        if (PATCH) {                                                                                                     \
+            int& slots = c->patch_slots[FROM_U ? 1 : 0];                                                                 \
+            if (slots == 0) FEP_TRY(resident_workgroups((const void*)element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB, JS>, TPB, \
+                                                        (size_t)c->lds_pad, c->device, &slots));                        \
+            grid = (unsigned)std::min<int64_t>(c->n_patch, slots);                                                       \
+        }                                                                                                                \
+        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB, JS>), dim3(grid),                           \
                            dim3(TPB), (size_t)c->lds_pad, st, c->n_e,                                                   \
                            c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,   \
                            c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts,                       \
                            PATCH ? nullptr : Kc, PATCH ? nullptr : fe, c->kc_aos ? 1 : 0, pa);                          \
     } while (0)
-    if (c->patch && c->patch_tpb == 512) {
-        if constexpr (NP == 6 && NQ == 7) { if (c->elem_geo) ELEM_LAUNCH_T(true, true, 512); else ELEM_LAUNCH_T(false, true, 512); }
-        else return FEP_ESTATE;                          // (P2 is the one element type with a 512-thread form)
-    }
-    else if (c->patch) { if (c->elem_geo) ELEM_LAUNCH(true, true); else ELEM_LAUNCH(false, true); }
-    else { if (c->elem_geo) ELEM_LAUNCH(true, false); else ELEM_LAUNCH(false, false); }
-#undef ELEM_LAUNCH
+#ifdef FEP_ABLATION
+#define ELEM_GEO_BOTH(PATCH, TPB, JS) do { if (c->elem_geo) ELEM_LAUNCH_T(true, PATCH, TPB, JS); else ELEM_LAUNCH_T(false, PATCH, TPB, JS); } while (0)
+#else       // the product instantiates ONE geometry form per element type and form of the route
+#define ELEM_GEO_BOTH(PATCH, TPB, JS)                                                                                    \
+    do {                                                                                                                 \
+        constexpr bool G = elem_geo_default(NP == 3 ? FEP_P1 : NP == 6 ? FEP_P2 : NP == 4 ? FEP_Q1 : NP == 8 ? FEP_Q2 : FEP_P4, PATCH); \
+        if (c->elem_geo != G) return FEP_ESTATE;                                                                         \
+        ELEM_LAUNCH_T(G, PATCH, TPB, JS);                                                                                \
+    } while (0)
+#endif
+#define ELEM_PATCH(TPB, JS) ELEM_GEO_BOTH(true, TPB, JS)
+    const int shape = c->patch_tpb * 8 + c->patch_js;
+    if (!c->patch) ELEM_GEO_BOTH(false, kBlock, 1);
+    else if (shape == 256 * 8 + 1) ELEM_PATCH(256, 1);
+    else if (NP == 6 && shape == 512 * 8 + 1) { if constexpr (NP == 6) ELEM_PATCH(512, 1); }
+    else if (NP == 15 && shape == 512 * 8 + 2) { if constexpr (NP == 15) ELEM_PATCH(512, 2); }
+#ifdef FEP_ABLATION
+    else if (NP == 8 && shape == 512 * 8 + 1) { if constexpr (NP == 8) ELEM_PATCH(512, 1); }
+    else if (NP == 8 && shape == 384 * 8 + 2) { if constexpr (NP == 8) ELEM_PATCH(384, 2); }
+#endif
+    else return FEP_ESTATE;
+#undef ELEM_PATCH
+#undef ELEM_GEO_BOTH
 #undef ELEM_LAUNCH_T
     HIP_TRY(hipGetLastError());
     return FEP_OK;
@@ -811,12 +974,16 @@ static int launch_reduce(fep_ctx* c, hipStream_t st, double* k_data, double* f_o
             hipLaunchKernelGGL(csr_reduce_pk_kernel, dim3(grid), dim3(kBlock), 0, st, c->n_wg_p1,
                                c->tstart, c->pkc, c->perm, c->Kc, k_data, c->n_count_blocks, c->blk_counts, counts_d, fa);
         else
+#ifdef FEP_ABLATION
         switch (c->csr_gathers) {
             case 2: CSR_REDUCE(2); break;
             case 6: CSR_REDUCE(6); break;
             case 8: CSR_REDUCE(8); break;
             default: CSR_REDUCE(4); break;
         }
+#else
+        CSR_REDUCE(4);                                   // (descriptor fields too wide for the packed form: four gathers in flight)
+#endif
 #undef CSR_REDUCE
         HIP_TRY(hipGetLastError());
         if (counts_done) *counts_done = counts_d != nullptr;
@@ -841,7 +1008,7 @@ static int launch_fixup(fep_ctx* c, hipStream_t st, double* k_data, double* f_ou
     const unsigned grid = nb_k + nb_f + (counts_d ? 1u : 0u);
     if (grid > 0) {
         hipLaunchKernelGGL(fixup_kernel, dim3(grid), dim3(kBlock), 0, st, (int)nb_k, c->n_open, c->pt_fix, c->pt_fixT, c->n_fopen, c->pt_ffix,
-                           c->pt_plist, c->Pc, c->Pf, k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d, c->patch_dbg);
+                           c->pt_plist, c->Pc, c->Pf, k_data, f_out, c->n_count_blocks, c->blk_counts, counts_d);
         HIP_TRY(hipGetLastError());
         if (counts_done) *counts_done = counts_d != nullptr;
     }
@@ -858,6 +1025,7 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
     FEP_TRY(prof_mark(c, st));
     if (counts_done) *counts_done = false;
     if ((k_data && ds) || (f_out && s)) {
+#ifdef FEP_ABLATION
         if (c->p1_fused && c->asm_from_nodes) {
             // opt-in (FEP_P1_ASM=nodes): assembly-only form of the one-kernel step, geometry from the tile's LDS-staged nodes
             // instead of the 48-byte record per staged element (same values bit for bit; 25 % fewer bytes but one barrier
@@ -884,14 +1052,15 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
             if (c->p1_fused_rng) ASM4(true, 1, 1); else ASM4(false, 1, 1);
 #undef ASM4
             if (counts_done) *counts_done = counts_d != nullptr;
-        } else if (c->p1_lds) {
+        } else
+#endif
+        if (c->p1_lds) {
             // operands + codes while gathering, then the same LDS holds the tile's output (4*TPB values + forces)
             const size_t lds = std::max((size_t)c->lds_L * 15 * sizeof(double) + (size_t)c->lds_C * sizeof(uint16_t),
                                         (size_t)c->tile * 3 * sizeof(double2));
             const int n_wg = c->n_wg_p1;
             const int chunk = (n_wg + 7) / 8;
-            static const bool verbose = std::getenv("FEP_VERBOSE") != nullptr;
-            if (verbose) {
+            if (verbose_on()) {
                 static bool once = false;
                 if (!once) {
                     once = true;
@@ -909,7 +1078,11 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
                            (const int4*)c->wg_rng, c->pk, c->tdesc, c->geo, k_data ? ds : nullptr,                       \
                            f_out ? s : nullptr, k_data, f_out, n_wg, c->n_count_blocks, c->blk_counts, counts_d);        \
     } while (0)
+#ifdef FEP_ABLATION
 #define NODE_LDS2(TPB, RNG, EPT) do { if (c->p1_pk) NODE_LDS3(TPB, RNG, EPT, true); else NODE_LDS3(TPB, RNG, EPT, false); } while (0)
+#else       // (a plan without packed descriptors never reaches the node route in the product: fep_ctx_create takes the element route)
+#define NODE_LDS2(TPB, RNG, EPT) do { if (!c->p1_pk) return FEP_ESTATE; NODE_LDS3(TPB, RNG, EPT, true); } while (0)
+#endif
 #define NODE_LDS(TPB)                                                                                                    \
     do {                                                                                                                 \
         if (c->lds_L > TPB) return FEP_ESTATE;          /* one staged element per lane (fep_host.h) */                  \
@@ -921,9 +1094,13 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
 #undef NODE_LDS3
             if (counts_done) *counts_done = counts_d != nullptr;
         } else {
+#ifdef FEP_ABLATION
             hipLaunchKernelGGL(p1_node_kernel, dim3(grid_for(c->n_blk, kBlock)), dim3(kBlock), 0, st,
                                c->n_blk, c->n_e, c->segptr, c->perm2, c->meta, c->ncol, c->geo,
                                k_data ? ds : nullptr, f_out ? s : nullptr, k_data, f_out);
+#else
+            return FEP_ESTATE;
+#endif
         }
         HIP_TRY(hipGetLastError());
     }
@@ -932,6 +1109,7 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
     return FEP_OK;
 }
 
+#ifdef FEP_ABLATION
 // node route for P2 / Q1 / Q2: assembly kernel
 static int launch_gn_node(fep_ctx* c, hipStream_t st, const double* ds, const double* s, double* k_data, double* f_out,
                           unsigned long long* counts_d, bool* counts_done) {
@@ -976,10 +1154,13 @@ static int launch_point(fep_ctx* c, hipStream_t st, const double* u, E0 e0, doub
     return FEP_OK;
 }
 
+#endif  // FEP_ABLATION
+
 // P1, one kernel per step (non-accepting calls with K and/or F wanted): p1_fused_kernel
 static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, const double* ep, double* eout, double* s,
                            double* ds, uint8_t* indp, double* k_data, double* f_out, unsigned long long* counts_d) {
     const bool dma = c->p1_dma;
+    (void)dma;
     const size_t Cp = dma ? ((size_t)c->lds_C + 127) & ~(size_t)127 : (size_t)c->lds_C;
     const size_t NLp = dma ? ((size_t)c->lds_NL + 63) & ~(size_t)63 : (size_t)c->lds_NL;
     const size_t lds_stage = (((size_t)c->lds_L * 15 * sizeof(double) + Cp * 2 + 15) & ~(size_t)15) + NLp * 2 * sizeof(double2);
@@ -987,7 +1168,11 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
     const int n_wg = c->n_wg_p1;
     const int chunk = (n_wg + 7) / 8;
     const bool full = eout || s || ds || indp;
+#ifdef FEP_ABLATION
 #define FUSED4(FULL, RNG, EPT, NPT)  do { if (dma) FUSED5(FULL, RNG, EPT, NPT, true); else FUSED5(FULL, RNG, EPT, NPT, false); } while (0)
+#else
+#define FUSED4(FULL, RNG, EPT, NPT)  FUSED5(FULL, RNG, EPT, NPT, false)
+#endif
 #define FUSED5(FULL, RNG, EPT, NPT, DMA)                                                                                 \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
@@ -1003,8 +1188,12 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
     } while (0)
 #define FUSED3(FULL, RNG) FUSED4(FULL, RNG, 1, 1)      /* L, NL <= 256 = threads: one staged element / node per lane (fep_host.h) */
     if (c->lds_L > 256 || c->lds_NL > 256) return FEP_ESTATE;
-    if (full) { if (c->p1_fused_rng) FUSED3(true, true); else FUSED3(true, false); }
-    else { if (c->p1_fused_rng) FUSED3(false, true); else FUSED3(false, false); }
+#ifdef FEP_ABLATION
+    if (full) { if (c->p1_fused_rng) FUSED3(true, true); else FUSED3(true, false); } else
+#else
+    if (full) return FEP_ESTATE;                         // (the product runs the one-kernel step for K,F-only calls: fused_mode 1)
+#endif
+    { if (c->p1_fused_rng) FUSED3(false, true); else FUSED3(false, false); }
 #undef FUSED3
 #undef FUSED4
 #undef FUSED5
@@ -1066,6 +1255,7 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
         FEP_TRY(launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, cnt, &counted));
         return counted ? FEP_OK : launch_counts(c, st, cnt);
     }
+#ifdef FEP_ABLATION
     if (c->gn) {
         if (k_data_d && !ds_d) {
             if (!c->ds_int) { FEP_TRY(scratch_alloc_allowed(st)); FEP_TRY(dmalloc(&c->ds_int, 9 * c->n_int)); }
@@ -1086,6 +1276,7 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
         FEP_TRY(launch_gn_node(c, st, ds_d, s_d, k_data_d, f_out_d, cnt, &counted));
         return counted ? FEP_OK : launch_counts(c, st, cnt);
     }
+#endif
     FEP_TRY(prof_mark(c, st));
     if (c->has_orphans && c->patch && f_out_d)                    // nodes of no element: no item writes their force
         HIP_TRY(hipMemsetAsync(f_out_d, 0, (size_t)c->n_dof * sizeof(double), st));
@@ -1114,10 +1305,12 @@ extern "C" int fep_assemble_dev(fep_ctx* c, void* stream, const double* ds_d, co
         FEP_TRY(prof_mark(c, st));
         return launch_p1_node(c, st, ds_d, s_d, k_data_d, f_out_d, nullptr, nullptr);
     }
+#ifdef FEP_ABLATION
     if (c->gn) {
         FEP_TRY(prof_mark(c, st));
         return launch_gn_node(c, st, ds_d, s_d, k_data_d, f_out_d, nullptr, nullptr);
     }
+#endif
     const E0 e0 = make_e0(nullptr);
     FEP_TRY(prof_mark(c, st));
     if (c->has_orphans && c->patch && f_out_d)
@@ -1220,6 +1413,17 @@ extern "C" int fep_scatter_f64(int device_id, void* stream, int64_t n, const dou
     if (n == 0) return FEP_OK;
     hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, src_d, src_idx_d,
                        dst_idx_d, dst_d);
+    HIP_TRY(hipGetLastError());
+    return FEP_OK;
+}
+
+extern "C" int fep_iface_sum_f64(int device_id, void* stream, int64_t n, const int32_t* loc_d, const int32_t* ptr_d,
+                                 const int32_t* src_d, const double* recv_d, double* f_d) {
+    if (n < 0 || (n > 0 && (!loc_d || !ptr_d || !src_d || !f_d))) return FEP_EINVAL;
+    FEP_TRY(fep_set_device(device_id));
+    if (n == 0) return FEP_OK;
+    hipLaunchKernelGGL(iface_sum_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, loc_d, ptr_d, src_d,
+                       recv_d, f_d);
     HIP_TRY(hipGetLastError());
     return FEP_OK;
 }

@@ -173,6 +173,38 @@ __device__ __forceinline__ void store_point(int64_t k, int64_t n, const double s
     if (indp) indp[k] = branch != 0;
 }
 
+// Row m of a point array ("rows x n", C order) at a 32-bit BYTE offset of the point: the row base is uniform (scalar
+// registers, scalar arithmetic), the offset one vector register shared by every access of the lane — the
+// `global_load/store ... v_off, s[base:base+1]` form.  With 64-bit indices every access carries its own address pair:
+// 13 point outputs + 2*NP gradients are 2*(13 + 2*NP) registers and as many 64-bit vector adds.  Callers guarantee
+// 8 * n < 2^32 (fep_ctx_create refuses n_int >= 2^27).
+// (The row base goes through readfirstlane: it is uniform already, but without the opaque step the compiler re-associates
+// base + m*stride + offset into per-lane 64-bit sums again.)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double ld_row(const double* __restrict__ base, int64_t row_stride, int m, unsigned byte_off) {
+    typedef const __attribute__((address_space(1))) char* gptr;        // (global address space: an integer cast alone gives a flat pointer)
+    const gptr row = reinterpret_cast<gptr>(uniform_u64(reinterpret_cast<uint64_t>(base + (int64_t)m * row_stride)));
+    return *reinterpret_cast<const __attribute__((address_space(1))) double*>(row + byte_off);
+}
+__device__ __forceinline__ void st_row(double* __restrict__ base, int64_t row_stride, int m, unsigned byte_off, double v) {
+    typedef __attribute__((address_space(1))) char* gptr;
+    const gptr row = reinterpret_cast<gptr>(uniform_u64(reinterpret_cast<uint64_t>(base + (int64_t)m * row_stride)));
+    *reinterpret_cast<__attribute__((address_space(1))) double*>(row + byte_off) = v;
+}
+__device__ __forceinline__ void store_point_off(unsigned kb, unsigned k32, int64_t n, const double s[4], const double d[6], int branch,
+                                                double* __restrict__ S, double* __restrict__ DS, uint8_t* __restrict__ indp) {
+    if (S) { st_row(S, n, 0, kb, s[0]); st_row(S, n, 1, kb, s[1]); st_row(S, n, 2, kb, s[2]); st_row(S, n, 3, kb, s[3]); }
+    if (DS) {   // row-major 3x3, m = 3i+j (DP:703)
+        st_row(DS, n, 0, kb, d[0]); st_row(DS, n, 1, kb, d[1]); st_row(DS, n, 2, kb, d[2]);
+        st_row(DS, n, 3, kb, d[1]); st_row(DS, n, 4, kb, d[3]); st_row(DS, n, 5, kb, d[4]);
+        st_row(DS, n, 6, kb, d[2]); st_row(DS, n, 7, kb, d[4]); st_row(DS, n, 8, kb, d[5]);
+    }
+    if (indp) indp[k32] = branch != 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // Mesh-free pointwise return map: construct_constitutive_problem (DP:604-757 / TSX:990-1157).
 // ---------------------------------------------------------------------------------------
@@ -300,23 +332,30 @@ inline __host__ __device__ void sym_block_index(int n_p, int a, int b, int& idx,
 }
 inline __host__ __device__ int sym_block_count(int n_p) { return (n_p / 2 + 1) * n_p; }   // upper bound on idx + 1
 
-template <int NP, int NQ, bool GEO = false, int TPB = kBlock> struct ElemCfg {
+// JS > 1 (patch form): phase 2 runs on JS lanes per (element, local node), each with 1/JS of the node's NJ stored blocks —
+// the 15-node element at JS = 2 on 512 threads keeps its 16-element patches (same LDS, same plan) at twice the waves per
+// CU and half the accumulators per lane.
+template <int NP, int NQ, bool GEO = false, int TPB = kBlock, int JS = 1> struct ElemCfg {
     static constexpr int maxpq = NP > NQ ? NP : NQ;
-    static constexpr int EB0 = (TPB / maxpq) >= TPB / 4 ? TPB / 4 : ((TPB / maxpq) >= TPB / 8 ? TPB / 8 : (TPB / maxpq));
+    static constexpr int T1 = TPB / JS;                 // lanes the (element, node) pairs of phase 2 may take
+    static constexpr int EB0 = (T1 / maxpq) >= T1 / 4 ? T1 / 4 : ((T1 / maxpq) >= T1 / 8 ? T1 / 8 : (T1 / maxpq));
     // with the coordinate staging of GEO the big elements take fewer per workgroup, so that the LDS still admits
     // as many resident workgroups as without it (P2: 4 per CU, Q2: 3)
     // (the 15-node element: 16 instead of 17, so that two workgroups with their gather codes fit a CU's LDS)
     // TPB = 512 (patch form; P2's default): twice the elements per workgroup — a patch four runs high with runs as long as
     // before — at the same waves per CU (two workgroups of eight waves)
-    static constexpr int S = TPB / kBlock;
+    static constexpr int S = T1 / kBlock > 0 ? T1 / kBlock : 1;
     static constexpr int EB = NP == 15 ? 16 * S : !GEO ? (NP == 6 && NQ == 7 && S == 2 ? 60 : EB0)
-                                                       : (NP == 6 && NQ == 7) ? 28 * S : (NP == 8 && NQ == 9) ? 24 * S : EB0;
+                                                       : (NP == 6 && NQ == 7) ? 28 * S : (NP == 8 && NQ == 9) ? (JS == 1 ? (T1 * 24) / kBlock : 24) : EB0;
     static constexpr int NQS = NQ | 1;                  // odd LDS stride: conflict-free ds_read_b64 over elements
     static constexpr int NPTS = EB * NQS;
     static constexpr int NJ = NP / 2 + 1;               // stored node-pair blocks (a, a+j mod NP) per local node
+    static constexpr int NJH = (NJ + JS - 1) / JS;      // ... per lane of phase 2
     // LDS image in doubles.  Phases 1-2: dphi (2*NP rows), w*DS (6), w*S (3) per point, then the per-element node
     // coordinates / displacements and the reference-element tables.  Phase 3 (patch route) re-uses the same memory:
-    // stored K_e blocks (NJ*NP*EB x 4), force pairs (NP*EB x 2), the patch's gather codes (uint16).
+    // stored K_e blocks as two planes of 16-byte pieces (first rows, second rows: NJ*NP*EB double2 each — a lane's store and
+    // its neighbour's are then 16 bytes apart, ds_write_b128 without bank conflicts; the interleaved 32-byte image of round 3
+    // cost two LDS passes per store), force pairs (NP*EB x 2), the patch's gather codes (uint16).
     static constexpr int kPts = (2 * NP + 9) * NPTS;
     static constexpr int kXY = 2 * NP * EB;             // one double2 per (local node, element)
     static constexpr int kTab = 2 * NP * NQ + NQ + (NQ & 1);
@@ -336,11 +375,32 @@ struct PatchArgs {
     const uint2* fitems; const uint16_t* fcodes;
     double* Pc; double* Pf;                             // partial blocks (4 doubles per slot) / partial forces (2)
     double* data; double* F;                            // CSR values / nodal force (either may be NULL)
-    int dbg;                                            // ablation switches (FEP_PATCH_DBG), 0 in production
+    int64_t n_patch;                                    // the grid is one wave of resident workgroups: each takes patches g, g + G, ...
+#ifdef FEP_ABLATION
+    unsigned long long* clk;                            // FEP_PHASE_CLK: 8 shader-clock stamps per workgroup (thread 0), or NULL
+#endif
 };
 
-template <int NP, int NQ, bool FROM_U, bool GEO, bool PATCH = false, int TPB = kBlock>
-__global__ void __launch_bounds__(TPB)
+// Phase stamps of the ablation build (thread 0 of every workgroup; the barriers keep the waves of a workgroup in step)
+#ifdef FEP_ABLATION
+#define FEP_STAMP_P(pa, p, i) do { if ((pa).clk && threadIdx.x == 0) (pa).clk[(size_t)(p) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FEP_STAMP_P(pa, p, i) do { } while (0)
+#endif
+
+// Waves per SIMD the patch form is compiled for (register budget = 512 / waves): the LDS image admits this many.
+#ifndef FEP_PATCH_WAVES
+#define FEP_PATCH_WAVES(NP, TPB) ((NP) == 15 ? 2 : (NP) == 8 ? 3 : 4)
+#endif
+// PATCH form: a PERSISTENT, software-pipelined workgroup (round 4).  The grid is one wave of resident workgroups; workgroup g
+// takes the patches g, g + G, g + 2G, ...  A patch's inputs are fetched one iteration ahead: its element / node ids during the
+// iteration before the previous one's end, its node coordinates and displacements and its points' previous plastic strain
+// while the patch before it is in phases 1-3 — the two dependent global round trips of the staging step (ids -> node data;
+// 22 % of a workgroup's life in the one-patch-per-workgroup form, in-kernel clocks: profiles/r04_ablation.md) and the wait for
+// the plastic strain at the top of phase 1 no longer stand in anybody's way.  Same arithmetic in the same order: results are
+// bit-identical to the one-patch form.
+template <int NP, int NQ, bool FROM_U, bool GEO, bool PATCH = false, int TPB = kBlock, int JS = 1>
+__global__ void __launch_bounds__(TPB, PATCH ? FEP_PATCH_WAVES(NP, TPB) : 1)
 element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                const double* __restrict__ dphi1, const double* __restrict__ dphi2, const double* __restrict__ weight,
                // GEO: geometry recomputed from the coordinates (xy interleaved) and the reference-element tables
@@ -355,12 +415,15 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                uint2* blk_counts,
                // outputs of phase 2 (kc_aos: all stored blocks of an element adjacent, see sym_block_index)
                double* __restrict__ Kc, double* __restrict__ fe, int kc_aos, PatchArgs pa) {
-    using C = ElemCfg<NP, NQ, GEO, TPB>;
+    using C = ElemCfg<NP, NQ, GEO, TPB, JS>;
     constexpr int EB = C::EB, NQS = C::NQS, NPTS = C::NPTS;
-    constexpr int NJ = C::NJ;                        // node-pair blocks (a, a+j mod NP) a lane of phase 2 computes
-    constexpr int kP12 = C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2) + (GEO ? C::kTab : 4);
-    constexpr int kLds = (PATCH && C::kPhase3 > kP12) ? C::kPhase3 : kP12;                  // phases 1-2 | phase 3, same memory
-    static_assert(EB * NQ <= TPB && EB * NP <= TPB, "one pass per phase");
+    constexpr int NJ = C::NJ;                        // stored node-pair blocks (a, a+j mod NP) per (element, local node)
+    constexpr int NJH = C::NJH;                      // ... of which a lane of phase 2 computes NJH (all of them unless JS > 1)
+    static_assert(PATCH || JS == 1, "the split of a node's blocks over JS lanes exists in the patch form only");
+    constexpr int kP12 = C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2);
+    constexpr int kImg = (PATCH && C::kPhase3 > kP12) ? C::kPhase3 : kP12;                  // phases 1-2 | phase 3, same memory
+    constexpr int kLds = kImg + (GEO ? C::kTab : 4);                                        // + the reference-element tables, kept for the kernel's life
+    static_assert(EB * NQ <= TPB && EB * NP * JS <= TPB, "one pass per phase");
     __shared__ __attribute__((aligned(16))) double lds[kLds];
     double (*d1s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds);
     double (*d2s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + NP * NPTS);
@@ -368,104 +431,262 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     double (*Ss)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + (2 * NP + 6) * NPTS);
     double2 (*cxy)[EB] = reinterpret_cast<double2 (*)[EB]>(lds + C::kPts);                       // node coordinates per element
     double2 (*cu)[EB] = reinterpret_cast<double2 (*)[EB]>(lds + C::kPts + (GEO ? C::kXY : 2));   // node displacements
-    double* t1 = lds + C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2);
+    double* t1 = lds + kImg;
     double* t2 = t1 + (GEO ? NP * NQ : 1);
     double* tw = t2 + (GEO ? NP * NQ : 1);
     uint32_t* codes32 = reinterpret_cast<uint32_t*>(lds + C::kKl + C::kFl);              // phase 3: behind the blocks and force pairs
     uint32_t* fcodes32 = reinterpret_cast<uint32_t*>(lds + C::kKl + C::kFl + C::kCodes);
+    __shared__ int32_t pel_s[PATCH ? 2 : 1][PATCH ? EB : 1];                             // element ids of the current / the next patch
 
-    const int t = threadIdx.x;
-    const int64_t e0blk = (int64_t)blockIdx.x * EB;     // COO form: the workgroup's elements are e0blk .. e0blk + nel - 1
-    const int64_t n_int = n_e * NQ;
-    // patch form: the elements are listed in pel (any ids, ascending); pdesc: 8 ints per patch (uniform address: scalar loads)
-    const int32_t* pd = PATCH ? pa.pdesc + (int64_t)blockIdx.x * 8 : nullptr;
-    const int item_off = PATCH ? pd[0] : 0, n_items = PATCH ? pd[1] : 0, code_off = PATCH ? pd[2] : 0, n_codes = PATCH ? pd[3] : 0;
-    const int fitem_off = PATCH ? pd[4] : 0, n_fitems = PATCH ? pd[5] : 0, fcode_off = PATCH ? pd[6] : 0, n_fcodes = PATCH ? pd[7] : 0;
-    const int nel = PATCH ? n_fcodes / NP : (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
+    const int64_t n_int_k = n_e * NQ;
+    const int64_t n_patch = PATCH ? pa.n_patch : 0, G = gridDim.x;
+    // The lane's indices are formed from an OPAQUE copy of the thread id, once in the prologue and again in every iteration of
+    // the patch loop: as loop invariants the compiler hoists every address derived from them out of the loop and keeps them
+    // in registers across it (210 instead of ~120 VGPRs, half the resident workgroups).
+#define FEP_LANE_INDICES(tid)                                                                                            \
+    int t = (tid);                                                                                                       \
+    asm volatile("" : "+v"(t));                                                                                          \
+    const int sa = t / EB, sel = t - sa * EB;          /* the lane's staging slot: (local node, element of the workgroup) */ \
+    const bool slot = (FROM_U || GEO) && t < NP * EB;                                                                    \
+    const int el1 = t / NQ, q1 = t - el1 * NQ          /* the lane's point in phase 1 */
 
-    __shared__ int32_t pel_s[PATCH ? EB : 1];
-    if (PATCH && t < EB) pel_s[t] = pa.pel[(int64_t)blockIdx.x * EB + t];
-    if (FROM_U || GEO) {
-        if (t < NP * EB) {
-            const int a = t / EB, el = t - a * EB;
-            const int64_t nd = PATCH ? pa.pnodes[((int64_t)blockIdx.x * NP + a) * EB + el]
-                                     : (el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0);
-            if (GEO) cxy[a][el] = *reinterpret_cast<const double2*>(xy + 2 * nd);
-            if (FROM_U) cu[a][el] = *reinterpret_cast<const double2*>(U + 2 * nd);
-        }
-        if (GEO) {
-            for (int i = t; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
-            for (int i = t; i < NQ; i += TPB) tw[i] = wf[i];
-        }
+    if (GEO) {
+        for (int i = threadIdx.x; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+        for (int i = threadIdx.x; i < NQ; i += TPB) tw[i] = wf[i];
     }
-    if (FROM_U || GEO || PATCH) __syncthreads();
+    // ---- prologue of the patch form: the first patch's inputs, and the ids of the second
+    int64_t p = blockIdx.x, pn = p + G;               // (patch indices: made scalar again at the top of every iteration, see there)
+    int32_t nd_n = 0, pel_n = -1;                      // NEXT patch: node id of the lane's staging slot, element id of slot t < EB
+    double2 xy_c = make_double2(0.0, 0.0), u_c = make_double2(0.0, 0.0);     // CURRENT patch: the slot's node data
+    double p_c[4] = {0.0, 0.0, 0.0, 0.0};              // CURRENT patch: the point's previous plastic strain
+    double m_c[4] = {0.0, 0.0, 0.0, 0.0};              // ... and its material parameters when they are per-point arrays
+    if (PATCH) {
+        FEP_LANE_INDICES(threadIdx.x);
+        const int64_t n_int = n_int_k;
+        int32_t nd_c = 0;
+        if (t < EB) pel_s[0][t] = pa.pel[p * EB + t];
+        if (slot) nd_c = pa.pnodes[(p * NP + sa) * EB + sel];
+        if (pn < n_patch) {
+            if (t < EB) pel_n = pa.pel[pn * EB + t];
+            if (slot) nd_n = pa.pnodes[(pn * NP + sa) * EB + sel];
+        }
+        if (slot && GEO) xy_c = *reinterpret_cast<const double2*>(xy + 2 * (int64_t)nd_c);
+        if (slot && FROM_U) u_c = *reinterpret_cast<const double2*>(U + 2 * (int64_t)nd_c);
+        __syncthreads();                               // pel_s[0]
+        if (FROM_U && ep && t < EB * NQ) {
+            const int32_t e = pel_s[0][el1];
+            if (e >= 0) {
+                const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
+                p_c[0] = ld_row(ep, n_int, 0, kb); p_c[1] = ld_row(ep, n_int, 1, kb); p_c[2] = ld_row(ep, n_int, 2, kb); p_c[3] = ld_row(ep, n_int, 3, kb);
+            }
+        }
+        if (FROM_U && !mu.on && t < EB * NQ) {
+            const int32_t e = pel_s[0][el1];
+            if (e >= 0) {
+                const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
+                m_c[0] = ld_row(shear, 0, 0, kb); m_c[1] = ld_row(bulk, 0, 0, kb); m_c[2] = ld_row(eta, 0, 0, kb); m_c[3] = ld_row(cc, 0, 0, kb);
+            }
+        }
+        asm volatile("" : "+v"(m_c[0]), "+v"(m_c[1]), "+v"(m_c[2]), "+v"(m_c[3]));
+        // (landed before the loop is entered, as the prefetches inside it are in front of phase 3: see there)
+        asm volatile("" : "+v"(xy_c.x), "+v"(xy_c.y), "+v"(u_c.x), "+v"(u_c.y));
+        asm volatile("" : "+v"(p_c[0]), "+v"(p_c[1]), "+v"(p_c[2]), "+v"(p_c[3]));
+        asm volatile("" : "+v"(nd_n), "+v"(pel_n));
+    }
 
-    // ---- phase 1 (one pass: EB * NQ <= TPB).  The point's operand loads are issued here, after the barrier: hoisting
-    // them (and the patch tables) in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
+    for (int it = 0; PATCH ? p < n_patch : it < 1; ++it) {
+    FEP_LANE_INDICES(threadIdx.x);
+    // (the row stride likewise: the row bases of ld_row / st_row are scalar registers, and as loop invariants two dozen of
+    // them stay allocated across the loop — past the scalar file they spill into vector registers)
+    int64_t n_int = n_int_k;
+    asm volatile("" : "+s"(n_int));
+    // the loop-carried patch indices are uniform, which the compiler no longer sees: without this the descriptor below is a
+    // VECTOR load and its wait (vmcnt(0)) at the top of every iteration drains the stores of the patch before
+    p = (int64_t)__builtin_amdgcn_readfirstlane((int)p);
+    pn = (int64_t)__builtin_amdgcn_readfirstlane((int)pn);
+    const int cb = it & 1;                             // pel_s buffer of the current patch
+    const int64_t e0blk = (int64_t)blockIdx.x * EB;    // COO form: the workgroup's elements are e0blk .. e0blk + nel - 1
+    // patch form: the elements are listed in pel (any ids, ascending); pdesc: 8 ints per patch (uniform address: scalar loads)
+    // (an explicit SCALAR load: inside the loop, behind the stores of the patch before, the compiler no longer proves the table
+    // read-only and falls back to a vector load whose wait — vmcnt(0) — would drain those stores at the top of every iteration)
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    v8i pdv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (PATCH) {
+        const int32_t* pd = pa.pdesc + p * 8;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pdv) : "s"(pd) : "memory");
+    }
+    const int item_off = pdv[0], n_items = pdv[1], code_off = pdv[2], n_codes = pdv[3];
+    const int fitem_off = pdv[4], n_fitems = pdv[5], fcode_off = pdv[6], n_fcodes = pdv[7];
+    const int nel = PATCH ? n_fcodes / NP : (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
+    const bool has_n = PATCH && pn < n_patch;
+    const int64_t pnn = pn + G;
+
+    FEP_STAMP_P(pa, p, 0);
+    // ---- staging: the current patch's node data from the registers the iteration before filled; the next patch's gathers and
+    // the ids of the one after it go out here and come back under phases 1-3
+    double2 xy_n = make_double2(0.0, 0.0), u_n = make_double2(0.0, 0.0);
+    int32_t nd_nn = 0, pel_nn = -1;
+    if (PATCH) {
+        if (slot) {
+            if (GEO) cxy[sa][sel] = xy_c;
+            if (FROM_U) cu[sa][sel] = u_c;
+        }
+        if (t < EB) pel_s[cb ^ 1][t] = pel_n;
+        if (has_n && slot) {
+            if (GEO) xy_n = *reinterpret_cast<const double2*>(xy + 2 * (int64_t)nd_n);
+            if (FROM_U) u_n = *reinterpret_cast<const double2*>(U + 2 * (int64_t)nd_n);
+        }
+        if (pnn < n_patch) {
+            if (t < EB) pel_nn = pa.pel[pnn * EB + t];
+            if (slot) nd_nn = pa.pnodes[(pnn * NP + sa) * EB + sel];
+        }
+    } else if (slot) {
+        const int64_t nd = sel < nel ? elem[(int64_t)sa * n_e + e0blk + sel] : 0;
+        if (GEO) cxy[sa][sel] = *reinterpret_cast<const double2*>(xy + 2 * nd);
+        if (FROM_U) cu[sa][sel] = *reinterpret_cast<const double2*>(U + 2 * nd);
+    }
+    if (PATCH) lds_barrier(); else if (FROM_U || GEO) __syncthreads();     // (patch form: nothing of this phase came from global memory)
+    FEP_STAMP_P(pa, p, 1);                                             // node data staged
+
+    // ---- phase 1 (one pass: EB * NQ <= TPB).  COO form: the point's operand loads are issued here, after the barrier: hoisting
+    // them in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
     int branch = 0;
-    const int el1 = t / NQ, q1 = t - el1 * NQ;
+    double p_n[4] = {0.0, 0.0, 0.0, 0.0};              // NEXT patch: the point's previous plastic strain
+    double m_n[4] = {0.0, 0.0, 0.0, 0.0};              // ... and its material parameters (arrays only)
     if (t < EB * NQ && el1 < nel) {
         const int el = el1, q = q1;
-        const int64_t k = PATCH ? (int64_t)pel_s[el] * NQ + q : e0blk * NQ + t;
+        const int64_t k = PATCH ? (int64_t)pel_s[cb][el] * NQ + q : e0blk * NQ + t;
+        const unsigned k32 = (unsigned)k, kb = k32 * 8u;             // byte offset of the point in a row (ld_row / st_row)
         const int li = el * NQS + q;
         double w;
-        double g1[NP], g2[NP];
+        double ev[3] = {0.0, 0.0, 0.0};
+        // Nodes in chunks of CH: gradients -> LDS image + strain sums (DP:1043).  All NP at once is 4*NP registers of
+        // loads in flight per lane; the 15-node element takes 5 at a time.
+        // The strain is written out in fused multiply-adds: which of two products the compiler fuses is its choice, and it
+        // chose differently in the 256- and the 512-thread instantiation (point outputs differed in the last bit).
+        constexpr int CH = NP == 15 ? 5 : NP;
         if (GEO) {
+            double g1[NP], g2[NP];
             double x[NP], y[NP];
 #pragma unroll
             for (int a = 0; a < NP; ++a) { const double2 c = cxy[a][el]; x[a] = c.x; y[a] = c.y; }
             geometry_at_q<NP>(t1, t2, tw[q], q, NQ, x, y, g1, g2, w);
-        } else {
-            w = weight[k];
-#pragma unroll
-            for (int a = 0; a < NP; ++a) { g1[a] = dphi1[(int64_t)a * n_int + k]; g2[a] = dphi2[(int64_t)a * n_int + k]; }
-        }
-#pragma unroll
-        for (int a = 0; a < NP; ++a) { d1s[a][li] = g1[a]; d2s[a][li] = g2[a]; }
-        double s[4], d[6];
-        if (FROM_U) {
-            double ev[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int a = 0; a < NP; ++a) {
-                const double2 u = cu[a][el];
-                // DP:1043.  Written out in fused multiply-adds: which of two products the compiler fuses is its choice, and
-                // it chose differently in the 256- and the 512-thread instantiation (point outputs differed in the last bit)
-                ev[0] = __builtin_fma(g1[a], u.x, ev[0]);
-                ev[1] = __builtin_fma(g2[a], u.y, ev[1]);
-                ev[2] += __builtin_fma(g1[a], u.y, g2[a] * u.x);
+                d1s[a][li] = g1[a]; d2s[a][li] = g2[a];
+                if (FROM_U) {
+                    const double2 u = cu[a][el];
+                    ev[0] = __builtin_fma(g1[a], u.x, ev[0]);
+                    ev[1] = __builtin_fma(g2[a], u.y, ev[1]);
+                    ev[2] += __builtin_fma(g1[a], u.y, g2[a] * u.x);
+                }
             }
-            double p[4] = {0.0, 0.0, 0.0, 0.0};
-            if (ep) { p[0] = ep[k]; p[1] = ep[n_int + k]; p[2] = ep[2 * n_int + k]; p[3] = ep[3 * n_int + k]; }
-            const double m_sh = mu.on ? mu.shear : shear[k], m_bu = mu.on ? mu.bulk : bulk[k];
-            const double m_eta = mu.on ? mu.eta : eta[k], m_c = mu.on ? mu.c : cc[k];
-            branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, accept != 0, s, d);
-            store_point(k, n_int, s, d, branch, S, DS, indp);
-            if (Eout) { Eout[k] = ev[0]; Eout[n_int + k] = ev[1]; Eout[2 * n_int + k] = ev[2]; }
+        } else {
+            w = ld_row(weight, 0, 0, kb);
+            // (a real loop for CH < NP: unrolled, the compiler hoists every chunk's loads to the top whatever stands between them)
+#pragma unroll 1
+            for (int a0 = 0; a0 < NP; a0 += CH) {
+                double g1[CH], g2[CH];
+#pragma unroll
+                for (int a = 0; a < CH; ++a) { g1[a] = ld_row(dphi1, n_int, a0 + a, kb); g2[a] = ld_row(dphi2, n_int, a0 + a, kb); }
+#pragma unroll
+                for (int a = 0; a < CH; ++a) {
+                    d1s[a0 + a][li] = g1[a]; d2s[a0 + a][li] = g2[a];
+                    if (FROM_U) {
+                        const double2 u = cu[a0 + a][el];
+                        ev[0] = __builtin_fma(g1[a], u.x, ev[0]);
+                        ev[1] = __builtin_fma(g2[a], u.y, ev[1]);
+                        ev[2] += __builtin_fma(g1[a], u.y, g2[a] * u.x);
+                    }
+                }
+            }
+        }
+        double s[4], d[6];
+        if (FROM_U) {
+            double pp[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ep) {
+                if (PATCH) { pp[0] = p_c[0]; pp[1] = p_c[1]; pp[2] = p_c[2]; pp[3] = p_c[3]; }
+                else { pp[0] = ld_row(ep, n_int, 0, kb); pp[1] = ld_row(ep, n_int, 1, kb); pp[2] = ld_row(ep, n_int, 2, kb); pp[3] = ld_row(ep, n_int, 3, kb); }
+            }
+            double m_sh, m_bu, m_eta, m_cc;
+            if (PATCH) {                                 // (patch form: per-point material arrays were fetched with the plastic strain)
+                m_sh = mu.on ? mu.shear : m_c[0]; m_bu = mu.on ? mu.bulk : m_c[1]; m_eta = mu.on ? mu.eta : m_c[2]; m_cc = mu.on ? mu.c : m_c[3];
+            } else {
+                m_sh = mu.on ? mu.shear : ld_row(shear, 0, 0, kb); m_bu = mu.on ? mu.bulk : ld_row(bulk, 0, 0, kb);
+                m_eta = mu.on ? mu.eta : ld_row(eta, 0, 0, kb); m_cc = mu.on ? mu.c : ld_row(cc, 0, 0, kb);
+            }
+            branch = dp_return_map(ev, e0.v, pp, m_sh, m_bu, m_eta, m_cc, accept != 0, s, d);
+            store_point_off(kb, k32, n_int, s, d, branch, S, DS, indp);
+            if (Eout) { st_row(Eout, n_int, 0, kb, ev[0]); st_row(Eout, n_int, 1, kb, ev[1]); st_row(Eout, n_int, 2, kb, ev[2]); }
             if (accept && ep && branch) {
-                ep[k] = p[0]; ep[n_int + k] = p[1]; ep[2 * n_int + k] = p[2]; ep[3 * n_int + k] = p[3];
+                st_row(ep, n_int, 0, kb, pp[0]); st_row(ep, n_int, 1, kb, pp[1]); st_row(ep, n_int, 2, kb, pp[2]); st_row(ep, n_int, 3, kb, pp[3]);
             }
         } else {
             if (DS) {
-                d[0] = DS[k]; d[1] = DS[n_int + k]; d[2] = DS[2 * n_int + k];
-                d[3] = DS[4 * n_int + k]; d[4] = DS[5 * n_int + k]; d[5] = DS[8 * n_int + k];
+                d[0] = ld_row(DS, n_int, 0, kb); d[1] = ld_row(DS, n_int, 1, kb); d[2] = ld_row(DS, n_int, 2, kb);
+                d[3] = ld_row(DS, n_int, 4, kb); d[4] = ld_row(DS, n_int, 5, kb); d[5] = ld_row(DS, n_int, 8, kb);
             } else { d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.0; }
-            if (S) { s[0] = S[k]; s[1] = S[n_int + k]; s[2] = S[2 * n_int + k]; } else { s[0] = s[1] = s[2] = 0.0; }
+            if (S) { s[0] = ld_row(S, n_int, 0, kb); s[1] = ld_row(S, n_int, 1, kb); s[2] = ld_row(S, n_int, 2, kb); } else { s[0] = s[1] = s[2] = 0.0; }
         }
 #pragma unroll
         for (int m = 0; m < 6; ++m) Ds[m][li] = w * d[m];                        // vD = w*ds, DP:1047
         Ss[0][li] = w * s[0]; Ss[1][li] = w * s[1]; Ss[2][li] = w * s[2];        // DP:1058
     }
-    if (FROM_U) count_branches(branch, nullptr, blk_counts);
-    if (pa.dbg & 64) __syncthreads(); else lds_barrier();              // (the point outputs' stores drain behind phase 2)
+    // the next patch's plastic strain: on its way while this patch is in phases 2-3 (its points belong to other elements than
+    // this patch's: an accepting call's stores above cannot reach them)
+    if (PATCH && FROM_U && ep && has_n && t < EB * NQ) {
+        const int32_t e = pel_s[cb ^ 1][el1];
+        if (e >= 0) {
+            const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
+            p_n[0] = ld_row(ep, n_int, 0, kb); p_n[1] = ld_row(ep, n_int, 1, kb); p_n[2] = ld_row(ep, n_int, 2, kb); p_n[3] = ld_row(ep, n_int, 3, kb);
+        }
+    }
+    if (PATCH && FROM_U && !mu.on && has_n && t < EB * NQ) {
+        const int32_t e = pel_s[cb ^ 1][el1];
+        if (e >= 0) {
+            const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
+            m_n[0] = ld_row(shear, 0, 0, kb); m_n[1] = ld_row(bulk, 0, 0, kb); m_n[2] = ld_row(eta, 0, 0, kb); m_n[3] = ld_row(cc, 0, 0, kb);
+        }
+    }
+    if (FROM_U) count_branches(branch, nullptr, blk_counts ? blk_counts + (PATCH ? p - blockIdx.x : 0) : nullptr);
+    // phase 3's tables: the lane's first items and its share of the gather codes are fetched HERE, in front of phase 2, whose
+    // arithmetic they come back under
+    // EVERY item descriptor of the patch (at most NP*NP*EB of them): phase 3 then issues no load between its stores — a load
+    // there is waited for with everything older than it, i.e. with the stores of the round before
+    constexpr int MAXIT = (NP * NP * EB + TPB - 1) / TPB, FIT = (NP * EB + TPB - 1) / TPB;
+    constexpr int IT = 4;                               // items a lane advances together (independent LDS chains)
+    constexpr int NG = (MAXIT + IT - 1) / IT;
+    const uint2* its = pa.items + item_off;
+    uint2 dsc[NG * IT], fdsc[FIT];
+    constexpr int CWPT = (NP * NP * EB / 2 + TPB) / TPB, FWPT = (NP * EB / 2 + TPB) / TPB;
+    uint32_t cpre[CWPT], fpre[FWPT];
+    if (PATCH) {
+#pragma unroll
+        for (int u = 0; u < NG * IT; ++u) { const int i = u * TPB + t; dsc[u] = (pa.data && u < MAXIT && i < n_items) ? its[i] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < FIT; ++u) { const int i = u * TPB + t; fdsc[u] = (pa.F && i < n_fitems) ? pa.fitems[fitem_off + i] : make_uint2(0u, 0u); }
+        // two codes per 32-bit word (every patch's codes start at an even offset; one pad entry may be read)
+        const uint32_t* cg = reinterpret_cast<const uint32_t*>(pa.codes + code_off);
+        const uint32_t* fg = reinterpret_cast<const uint32_t*>(pa.fcodes + fcode_off);
+#pragma unroll
+        for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; cpre[r] = (pa.data && i < (n_codes + 1) / 2) ? cg[i] : 0u; }
+#pragma unroll
+        for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
+    }
+    lds_barrier();                                                     // (the point outputs' stores drain behind phase 2)
+    FEP_STAMP_P(pa, p, 2);                                             // phase 1 done
 
-    // ---- phase 2 (one pass: NP * EB <= TPB) ----------------------------------------
-    double kk[NJ][4];
+    // ---- phase 2 (one pass: NP * EB * JS <= TPB) ----------------------------------
+    // lane (h, a, el): the blocks j = h*NJH .. of the (element, node) pair; h = 0 also sums the force pair
+    double kk[NJH][4];
     double f0 = 0.0, f1 = 0.0;
-    const int a = t / EB, el = t - a * EB;
-    const bool lane2 = t < NP * EB && el < nel;
+    const int ha = t / EB, el = t - ha * EB;
+    const int h = JS == 1 ? 0 : ha / NP, a = JS == 1 ? ha : ha - h * NP;
+    const int j0 = h * NJH;
+    const bool lane2 = t < NP * EB * JS && el < nel;
     if (lane2) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { kk[j][0] = 0.0; kk[j][1] = 0.0; kk[j][2] = 0.0; kk[j][3] = 0.0; }
+        for (int j = 0; j < NJH; ++j) { kk[j][0] = 0.0; kk[j][1] = 0.0; kk[j][2] = 0.0; kk[j][3] = 0.0; }
 #pragma unroll 1
         for (int q = 0; q < NQ; ++q) {
             const int li = el * NQS + q;
@@ -478,11 +699,14 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 #if FEP_P2_FMA
             // every product goes into its accumulator with one fused multiply-add (two per entry and point instead of
             // multiply, multiply-add, add)
-            f0 = __builtin_fma(a1, Ss[0][li], __builtin_fma(a2, Ss[2][li], f0));
-            f1 = __builtin_fma(a2, Ss[1][li], __builtin_fma(a1, Ss[2][li], f1));
+            if (JS == 1 || h == 0) {
+                f0 = __builtin_fma(a1, Ss[0][li], __builtin_fma(a2, Ss[2][li], f0));
+                f1 = __builtin_fma(a2, Ss[1][li], __builtin_fma(a1, Ss[2][li], f1));
+            }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int b = a + j >= NP ? a + j - NP : a + j;
+            for (int j = 0; j < NJH; ++j) {
+                const int jj = j0 + j;
+                const int b = a + jj >= NP ? a + jj - NP : a + jj;
                 const double b1 = d1s[b][li], b2 = d2s[b][li];
                 kk[j][0] = __builtin_fma(r00, b1, __builtin_fma(r02, b2, kk[j][0]));
                 kk[j][1] = __builtin_fma(r01, b2, __builtin_fma(r02, b1, kk[j][1]));
@@ -490,11 +714,14 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                 kk[j][3] = __builtin_fma(r11, b2, __builtin_fma(r12, b1, kk[j][3]));
             }
 #else
-            f0 += a1 * Ss[0][li] + a2 * Ss[2][li];
-            f1 += a2 * Ss[1][li] + a1 * Ss[2][li];
+            if (JS == 1 || h == 0) {
+                f0 += a1 * Ss[0][li] + a2 * Ss[2][li];
+                f1 += a2 * Ss[1][li] + a1 * Ss[2][li];
+            }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int b = a + j >= NP ? a + j - NP : a + j;
+            for (int j = 0; j < NJH; ++j) {
+                const int jj = j0 + j;                                       // (jj >= NJ on the last lane group of an uneven
+                const int b = a + jj >= NP ? a + jj - NP : a + jj;           //  split: computed on a valid node, never stored)
                 const double b1 = d1s[b][li], b2 = d2s[b][li];
                 kk[j][0] += r00 * b1 + r02 * b2;
                 kk[j][1] += r01 * b2 + r02 * b1;
@@ -509,7 +736,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         const int64_t e = e0blk + el;
         if (Kc) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < NJH; ++j) {                                  // (JS == 1 here: NJH == NJ)
                 if (NP % 2 == 0 && j == NP / 2 && a >= NP / 2) continue;     // held by the lane of node a - NP/2
                 double2* dst = reinterpret_cast<double2*>(Kc + (kc_aos ? (e * (NJ * NP) + a * NJ + j) : ((int64_t)(j * NP + a) * n_e + e)) * 4);
                 dst[0] = make_double2(kk[j][0], kk[j][1]);
@@ -521,72 +748,88 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     }
 
     // ---- phase 3 (patch route) --------------------------------------------------------
-    double2* Kl2 = reinterpret_cast<double2*>(lds);                    // stored block (idx, el) at [(idx * EB + el) * 2 + {0, 1}]
+    // stored block (idx, el): first row at Kr0[idx * EB + el], second row at Kr1[idx * EB + el] (two planes, see ElemCfg)
+    double2* Kr0 = reinterpret_cast<double2*>(lds);
+    double2* Kr1 = Kr0 + NJ * NP * EB;
     double2* fl2 = reinterpret_cast<double2*>(lds + C::kKl);           // force pair (a, el) at [a * EB + el]
     const uint16_t* codes_l = reinterpret_cast<const uint16_t*>(codes32);
     const uint16_t* fcodes_l = reinterpret_cast<const uint16_t*>(fcodes32);
-    // the lane's first items and its share of the gather codes are fetched before the barrier (independent of phase 2)
-    constexpr int IT = 4;                               // items per lane and round
-    const uint2* its = pa.items + item_off;
-    uint2 dsc[IT];
-#pragma unroll
-    for (int u = 0; u < IT; ++u) { const int it = u * TPB + t; dsc[u] = (pa.data && it < n_items) ? its[it] : make_uint2(0u, 0u); }
-    constexpr int CWPT = (NP * NP * EB / 2 + TPB) / TPB, FWPT = (NP * EB / 2 + TPB) / TPB;
-    uint32_t cpre[CWPT], fpre[FWPT];
-    {   // two codes per 32-bit word (every patch's codes start at an even offset; one pad entry may be read)
-        const uint32_t* cg = reinterpret_cast<const uint32_t*>(pa.codes + code_off);
-        const uint32_t* fg = reinterpret_cast<const uint32_t*>(pa.fcodes + fcode_off);
-#pragma unroll
-        for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; cpre[r] = (pa.data && i < (n_codes + 1) / 2) ? cg[i] : 0u; }
-#pragma unroll
-        for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
-    }
-    if (pa.dbg & 64) __syncthreads(); else lds_barrier();              // every lane is done reading the phase-2 operands
+    FEP_STAMP_P(pa, p, 3);                                             // phase 2 done (thread 0's wave)
+    lds_barrier();                                                     // every lane is done reading the phase-2 operands
+    FEP_STAMP_P(pa, p, 4);
     if (lane2) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (NP % 2 == 0 && j == NP / 2 && a >= NP / 2) continue;
-            double2* dst = Kl2 + ((j * NP + a) * EB + el) * 2;
-            dst[0] = make_double2(kk[j][0], kk[j][1]);
-            dst[1] = make_double2(kk[j][2], kk[j][3]);
+        for (int j = 0; j < NJH; ++j) {
+            const int jj = j0 + j;
+            if (JS > 1 && jj >= NJ) continue;
+            if (NP % 2 == 0 && jj == NP / 2 && a >= NP / 2) continue;
+            const int pos = (jj * NP + a) * EB + el;
+            Kr0[pos] = make_double2(kk[j][0], kk[j][1]);
+            Kr1[pos] = make_double2(kk[j][2], kk[j][3]);
         }
-        fl2[a * EB + el] = make_double2(f0, f1);
+        if (JS == 1 || h == 0) fl2[a * EB + el] = make_double2(f0, f1);
     }
 #pragma unroll
     for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; if (i < (n_codes + 1) / 2) codes32[i] = cpre[r]; }
 #pragma unroll
     for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; if (i < (n_fcodes + 1) / 2) fcodes32[i] = fpre[r]; }
-    if (pa.dbg & 64) __syncthreads(); else lds_barrier();
-    if (pa.data && !(pa.dbg & 4)) {
+    lds_barrier();
+    FEP_STAMP_P(pa, p, 5);                                             // K_e image and codes in LDS
+    // The next patch's prefetched values LAND here, in front of this patch's stores: a first use in the next iteration would
+    // make the compiler wait for every memory operation of this one (its count across the back edge is conservative:
+    // vmcnt(0)), i.e. for the stores below to drain.  Here the loads are one to two phases old.
+    if (PATCH) {
+        asm volatile("" : "+v"(xy_n.x), "+v"(xy_n.y), "+v"(u_n.x), "+v"(u_n.y));
+        asm volatile("" : "+v"(p_n[0]), "+v"(p_n[1]), "+v"(p_n[2]), "+v"(p_n[3]));
+        asm volatile("" : "+v"(m_n[0]), "+v"(m_n[1]), "+v"(m_n[2]), "+v"(m_n[3]));
+        asm volatile("" : "+v"(nd_nn), "+v"(pel_nn));
+    }
+    if (pa.data) {
         double2* data2 = reinterpret_cast<double2*>(pa.data);
         double2* Pc2 = reinterpret_cast<double2*>(pa.Pc);
-        for (int base = 0; base < n_items; base += IT * TPB) {
-            if (base > 0) {
 #pragma unroll
-                for (int u = 0; u < IT; ++u) { const int it = base + u * TPB + t; dsc[u] = it < n_items ? its[it] : make_uint2(0u, 0u); }
+        for (int g = 0; g < NG; ++g) {
+            if (g * IT * TPB >= n_items) break;                        // (uniform)
+            // The lane's IT items advance together, contribution k of each in one round: IT independent chains
+            // (code -> the block's two 16-byte rows) in flight instead of one — the loop is a chain of LDS round trips.
+            // A lane's item that has run out re-reads its last contribution and drops it: every sum is the same
+            // sequence of additions as a per-item loop (0 + c_0 + c_1 + ...).
+            int off[IT], cnt[IT], kmax = 0;
+            double a00[IT], a01[IT], a10[IT], a11[IT];
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const bool on = (g * IT + u) * TPB + t < n_items;
+                off[u] = (int)(dsc[g * IT + u].x & 8191u);
+                cnt[u] = on ? (int)((dsc[g * IT + u].x >> 13) & 63u) + 1 : 0;
+                kmax = cnt[u] > kmax ? cnt[u] : kmax;
+                a00[u] = 0.0; a01[u] = 0.0; a10[u] = 0.0; a11[u] = 0.0;
+            }
+            for (int k = 0; k < kmax; ++k) {
+                unsigned code[IT];
+                double2 r0[IT], r1[IT];
+#pragma unroll
+                for (int u = 0; u < IT; ++u) { const int kc = k < cnt[u] ? k : (cnt[u] > 0 ? cnt[u] - 1 : 0); code[u] = codes_l[off[u] + kc]; }
+#pragma unroll
+                for (int u = 0; u < IT; ++u) { r0[u] = Kr0[code[u] >> 1]; r1[u] = Kr1[code[u] >> 1]; }
+#pragma unroll
+                for (int u = 0; u < IT; ++u) {
+                    if (k < cnt[u]) {
+                        const bool tr = code[u] & 1u;
+                        a00[u] += r0[u].x; a01[u] += tr ? r1[u].x : r0[u].y; a10[u] += tr ? r0[u].y : r1[u].x; a11[u] += r1[u].y;
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
-                if (base + u * TPB + t >= n_items) continue;
-                const uint32_t x = dsc[u].x, y = dsc[u].y;
-                const int off = (int)(x & 8191u), cnt = (int)((x >> 13) & 63u) + 1;
-                double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-                for (int k = 0; k < cnt; ++k) {
-                    const unsigned code = codes_l[off + k];
-                    const double2* src = Kl2 + (code >> 1) * 2;
-                    const double2 r0 = src[0], r1 = src[1];
-                    const bool tr = code & 1u;
-                    a00 += r0.x; a01 += tr ? r1.x : r0.y; a10 += tr ? r0.y : r1.x; a11 += r1.y;
-                }
+                if (cnt[u] == 0) continue;
+                const uint32_t x = dsc[g * IT + u].x, y = dsc[g * IT + u].y;
                 if (x >> 31) {                                         // partial: slot y of the side buffer
-                    if ((pa.dbg & 2) && a00 != 1.2345e300) continue;
-                    Pc2[2 * (int64_t)y] = make_double2(a00, a01);
-                    Pc2[2 * (int64_t)y + 1] = make_double2(a10, a11);
+                    Pc2[2 * (int64_t)y] = make_double2(a00[u], a01[u]);
+                    Pc2[2 * (int64_t)y + 1] = make_double2(a10[u], a11[u]);
                 } else {                                               // finished CSR block: its two rows
-                    if ((pa.dbg & 1) && a00 != 1.2345e300) continue;
                     const int deg = (int)((x >> 19) & 4095u);
-                    data2[y] = make_double2(a00, a01);
-                    data2[(int64_t)y + deg] = make_double2(a10, a11);
+                    data2[y] = make_double2(a00[u], a01[u]);
+                    data2[(int64_t)y + deg] = make_double2(a10[u], a11[u]);
                 }
             }
         }
@@ -594,14 +837,26 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     if (pa.F) {
         double2* F2 = reinterpret_cast<double2*>(pa.F);
         double2* Pf2 = reinterpret_cast<double2*>(pa.Pf);
-        for (int it = t; it < n_fitems; it += TPB) {
-            const uint2 d = pa.fitems[fitem_off + it];
+#pragma unroll
+        for (int u = 0; u < FIT; ++u) {
+            if (u * TPB + t >= n_fitems) continue;
+            const uint2 d = fdsc[u];
             const int off = (int)(d.x & 8191u), cnt = (int)((d.x >> 13) & 63u) + 1;
             double g0 = 0.0, g1 = 0.0;
             for (int k = 0; k < cnt; ++k) { const double2 v = fl2[fcodes_l[off + k]]; g0 += v.x; g1 += v.y; }
             if (d.x >> 31) Pf2[d.y] = make_double2(g0, g1); else F2[d.y] = make_double2(g0, g1);
         }
     }
+    FEP_STAMP_P(pa, p, 6);                                             // thread 0's wave has issued its last store
+    // ---- next patch: what was fetched under this one becomes current; the image must have been read before it is overwritten
+    lds_barrier();
+    xy_c = xy_n; u_c = u_n;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { p_c[m] = p_n[m]; m_c[m] = m_n[m]; }
+    nd_n = nd_nn; pel_n = pel_nn;
+    p = pn; pn = pnn;
+    }
+#undef FEP_LANE_INDICES
 }
 
 // Second kernel of the patch route: one lane per UPPER open block (a node pair on a patch boundary, row node <= column
@@ -613,7 +868,7 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, const uint
              int64_t n_fopen, const uint4* __restrict__ ffix,
              const int32_t* __restrict__ plist, const double* __restrict__ Pc, const double* __restrict__ Pf,
              double* __restrict__ data, double* __restrict__ F,
-             int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out, int dbg) {
+             int n_count_blocks, const uint2* __restrict__ blk_counts, unsigned long long* __restrict__ counts_out) {
     const int g = counts_out != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     if (g < 0) { sum_block_counts(n_count_blocks, blk_counts, counts_out); return; }
     if (g < nb_k) {
@@ -623,8 +878,7 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, const uint
         const int cnt = (int)(f.y >> 16), deg = (int)(f.y & 0xffffu);
         const double2* P2 = reinterpret_cast<const double2*>(Pc);
         double a00, a01, a10, a11;
-        if (dbg & 32) { a00 = (double)f.z; a01 = (double)f.w; a10 = 1.0; a11 = 2.0; }
-        else if (cnt <= 2) {
+        if (cnt <= 2) {
             const double2 p0 = P2[2 * (int64_t)f.z], p1 = P2[2 * (int64_t)f.z + 1];
             a00 = 0.0 + p0.x; a01 = 0.0 + p0.y; a10 = 0.0 + p1.x; a11 = 0.0 + p1.y;
             if (cnt == 2) {
@@ -639,12 +893,11 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, const uint
                 a00 += p0.x; a01 += p0.y; a10 += p1.x; a11 += p1.y;
             }
         }
-        if ((dbg & 8) && a00 != 1.2345e300) return;
         const uint2 ft = fixT[i];
         double2* data2 = reinterpret_cast<double2*>(data);
         data2[f.x] = make_double2(a00, a01);
         data2[(int64_t)f.x + deg] = make_double2(a10, a11);
-        if (ft.x != 0xffffffffu && !(dbg & 16)) {                      // the mirror block (column node, row node): the transpose
+        if (ft.x != 0xffffffffu) {                      // the mirror block (column node, row node): the transpose
             data2[ft.x] = make_double2(a00, a10);
             data2[(int64_t)ft.x + ft.y] = make_double2(a01, a11);
         }
@@ -1647,6 +1900,21 @@ scatter_kernel(int64_t n, const double* __restrict__ src, const int32_t* __restr
                const int32_t* __restrict__ dst_idx, double* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) dst[dst_idx[i]] = src[src_idx[i]];
+}
+
+// Neighbour-only interface exchange, last step (sharding.py): interface DOF i (local DOF loc[i]) becomes
+// 0 + c_0 + c_1 + ... over its holders in ascending rank order, c = this rank's own value (src < 0) or the value a
+// neighbour sent (recv[src]).  The same sequence of additions on every holder: the same bits everywhere.
+__global__ void __launch_bounds__(kBlock)
+iface_sum_kernel(int64_t n, const int32_t* __restrict__ loc, const int32_t* __restrict__ ptr, const int32_t* __restrict__ src,
+                 const double* __restrict__ recv, double* __restrict__ f) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t d = loc[i];
+    const double own = f[d];
+    double acc = 0.0;
+    for (int32_t k = ptr[i]; k < ptr[i + 1]; ++k) { const int32_t s = src[k]; acc += s < 0 ? own : recv[s]; }
+    f[d] = acc;
 }
 
 }  // namespace fep

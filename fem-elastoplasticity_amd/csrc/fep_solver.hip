@@ -923,12 +923,12 @@ static int solver_create_impl(fep_solver** out, int device_id, int64_t n_n, cons
     FEP_TRY(fep_set_device(device_id));
     fep_solver* s = new (std::nothrow) fep_solver();
     if (!s) return FEP_ENOMEM;
-    if (const char* sm = std::getenv("FEP_AMG_SMOOTHER")) s->cheb = std::strcmp(sm, "jacobi") != 0;
-    if (const char* al = std::getenv("FEP_AMG_CHEB_ALPHA")) { const double v = std::atof(al); if (v > 1.0) s->cheb_alpha = v; }
-    if (const char* f32 = std::getenv("FEP_AMG_FP32")) s->fp32 = std::strcmp(f32, "0") != 0;
-    if (const char* bt = std::getenv("FEP_AMG_BLOCK_TRANSFERS")) s->block_transfers = std::strcmp(bt, "0") != 0;
-    if (const char* tl = std::getenv("FEP_AMG_TAIL")) s->tail = std::strcmp(tl, "0") != 0;
-    if (const char* sf = std::getenv("FEP_AMG_CHEB_SAFETY")) { const double v = std::atof(sf); if (v >= 1.0) s->cheb_safety = v; }
+    if (const char* sm = fep_tune("FEP_AMG_SMOOTHER")) s->cheb = std::strcmp(sm, "jacobi") != 0;
+    if (const char* al = fep_tune("FEP_AMG_CHEB_ALPHA")) { const double v = std::atof(al); if (v > 1.0) s->cheb_alpha = v; }
+    if (const char* f32 = fep_tune("FEP_AMG_FP32")) s->fp32 = std::strcmp(f32, "0") != 0;
+    if (const char* bt = fep_tune("FEP_AMG_BLOCK_TRANSFERS")) s->block_transfers = std::strcmp(bt, "0") != 0;
+    if (const char* tl = fep_tune("FEP_AMG_TAIL")) s->tail = std::strcmp(tl, "0") != 0;
+    if (const char* sf = fep_tune("FEP_AMG_CHEB_SAFETY")) { const double v = std::atof(sf); if (v >= 1.0) s->cheb_safety = v; }
     s->device = device_id; s->n_n = n_n; s->n_dof = n_dof; s->n_blk = n_blk;
     s->ip0.assign(indptr_h, indptr_h + n_dof + 1);
     s->ix0.assign(indices_h, indices_h + indptr_h[n_dof]);
@@ -984,7 +984,7 @@ namespace {
 // iterations already enqueued still run their passes: with a fixed batch of 10 a two-digit multigrid solve of ~80 iterations
 // threw 4.5 of them away on average.  Undershooting costs one more 48-byte read-back, overshooting whole iterations, hence 3/4.
 inline int next_batch(int check_every, double rr_prev, int n_prev, double rr, double target) {
-    static const bool fixed = std::getenv("FEP_PCG_FIXED_BATCH") != nullptr;      // A/B switch: always check_every
+    static const bool fixed = fep_tune("FEP_PCG_FIXED_BATCH") != nullptr;      // A/B switch: always check_every
     if (fixed) return check_every;
     if (!(rr_prev > 0.0) || !(rr > 0.0) || n_prev <= 0 || !(rr < rr_prev) || !(target > 0.0)) return check_every;
     if (rr <= target) return 1;
@@ -1295,7 +1295,7 @@ static int enable_refresh_impl(fep_solver* s) {
     // products (290 M at 1 M DOFs) are listed on the device from those patterns (device_plan).  FEP_AMG_PLAN=host lists them on
     // the host as well (fep_host.h product_plan, the form the sanitizer driver replays) and uploads the index pairs: the same
     // term lists, 0.8 s more of set-up at 1 M DOFs.
-    const char* pm = std::getenv("FEP_AMG_PLAN");
+    const char* pm = fep_tune("FEP_AMG_PLAN");
     const bool host_plan = pm && std::strcmp(pm, "host") == 0;
     int rc = FEP_OK;
     auto up = [&](int32_t** dst, const std::vector<int32_t>& v) {

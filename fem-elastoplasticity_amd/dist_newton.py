@@ -27,13 +27,21 @@ from .sharding import ShardedContext
 from .tables import _coerce, element_tables
 
 
-def _allreduce_(t, group=None):
-    """In-place sum over the ranks; device tensors go through the host when the backend is gloo (rehearsal on one GPU)."""
+def _allreduce_(t, group=None, device=None):
+    """In-place sum over the ranks.  The tensor goes where the backend can reduce it: device tensors through the host when
+    the backend is gloo (rehearsal on one GPU), HOST tensors through the rank's device (`device`, default: torch's current
+    one) when it is not — an RCCL process group rejects CPU tensors."""
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
-    if t.is_cuda and dist.get_backend(group) == 'gloo':
+    gloo = dist.get_backend(group) == 'gloo'
+    if t.is_cuda and gloo:
         tmp = t.cpu()
+        dist.all_reduce(tmp, group=group)
+        t.copy_(tmp)
+    elif not t.is_cuda and not gloo:
+        tmp = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
         dist.all_reduce(tmp, group=group)
         t.copy_(tmp)
     else:
@@ -223,7 +231,7 @@ class _ShardOps:
             return v.cpu().numpy()
         g = t.zeros(self.n_dof_global, dtype=t.float64)
         g[t.from_numpy(self.cg.dofs_global)] = (v * self.cg.w).cpu()
-        return _allreduce_(g, self.group).numpy()
+        return _allreduce_(g, self.group, self.dev).numpy()
 
     def nodal(self, q_int, elem_global, weight_local):
         """transform (DP:760-816) of a point field: numerators and denominators summed over the ranks, global nodal array."""
@@ -237,7 +245,7 @@ class _ShardOps:
         wq = w * q_int.cpu().numpy().ravel()
         f = t.from_numpy(np.stack([np.bincount(nodes.ravel(), weights=np.tile(wq, n_p), minlength=n_n),
                                    np.bincount(nodes.ravel(), weights=np.tile(w, n_p), minlength=n_n)]))
-        _allreduce_(f, self.group)
+        _allreduce_(f, self.group, self.dev)
         return (f[0] / f[1]).numpy()
 
     def close(self):

@@ -254,6 +254,14 @@ class MeshContext:
             self._pattern = (ip, ix)
         return self._pattern
 
+    def kernel_names(self, which=0):
+        """The kernels one step launches, named as rocprofv3 prints them, joined by ' + ' (which = 0: every output,
+        1: the K,F-only step of a Newton iterate)."""
+        import ctypes
+        buf = ctypes.create_string_buffer(512)
+        _lib.check(_lib.lib().fep_ctx_kernel_names(self._h, int(which), buf, 512), 'fep_ctx_kernel_names')
+        return buf.value.decode()
+
     def csr(self, data):
         ip, ix = self.pattern()
         return ssp.csr_matrix((data, ix, ip), shape=(self.n_dof, self.n_dof))

@@ -293,23 +293,31 @@ class KrylovSolver:
                                      rho0=None if k_dev is None else self._rho_dev(k_dev))
         t1 = time.perf_counter()
         l = _lib.lib()
-        _lib.check(l.fep_solver_amg_clear(self._h), 'fep_solver_amg_clear')
-        for lv in levels:
-            mats = []
-            for M in (lv['P'], lv['R'], lv['A'], lv['D']):
-                if M is None:
-                    mats += [None, None, None]
-                else:
-                    mats += [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
-                             np.ascontiguousarray(M.data, dtype=np.float64)]
-            _lib.check(l.fep_solver_amg_push_level(self._h, lv['P'].shape[0], lv['P'].shape[1], *[_lib.ptr(m) for m in mats],
-                                                   float(lv['omega']), int(lv['last'])), 'fep_solver_amg_push_level')
+
+        def push_levels():
+            _lib.check(l.fep_solver_amg_clear(self._h), 'fep_solver_amg_clear')
+            for lv in levels:
+                mats = []
+                for M in (lv['P'], lv['R'], lv['A'], lv['D']):
+                    if M is None:
+                        mats += [None, None, None]
+                    else:
+                        mats += [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+                                 np.ascontiguousarray(M.data, dtype=np.float64)]
+                _lib.check(l.fep_solver_amg_push_level(self._h, lv['P'].shape[0], lv['P'].shape[1], *[_lib.ptr(m) for m in mats],
+                                                       float(lv['omega']), int(lv['last'])), 'fep_solver_amg_push_level')
+        push_levels()
         self.amg_levels = [(K.shape[0], K.nnz)] + [lv['size'] for lv in levels]
         self.amg_refresh = False
         t2 = time.perf_counter()
         if refresh:
             rc = l.fep_solver_amg_enable_refresh(self._h)
-            if rc != -5:                                 # FEP_ERANGE: too large a coarsest level / product: the operators of K_ref stay
+            if rc == -5:
+                # FEP_ERANGE: too large a coarsest level (hierarchy untouched) or a product plan beyond 32-bit counts, found
+                # while the plans were built (hierarchy dropped, include/fep.h): the levels are pushed again and the solves
+                # keep the coarse operators of K_ref
+                push_levels()
+            else:
                 _lib.check(rc, 'fep_solver_amg_enable_refresh')
                 self.amg_refresh = True
         self.amg_seconds = {'hierarchy': t1 - t0, 'upload': t2 - t1, 'refresh_plans': time.perf_counter() - t2}

@@ -56,6 +56,9 @@ typedef struct fep_ctx fep_ctx;
 
 /* ---- library ------------------------------------------------------------------------ */
 int         fep_version(void);                 /* ABI version, currently 1 */
+int         fep_build_is_ablation(void);       /* 1: built with -DFEP_ABLATION (measurement switches by environment variable, phase
+                                                * clocks; tools/ only), 0: the product library, which reads FEP_ROUTE,
+                                                * FEP_VALIDATE_PLAN, FEP_VERBOSE, FEP_HOST_THREADS, FEP_COPY_THREADS and nothing else */
 const char* fep_strerror(int code);
 int         fep_last_hip_error(void);          /* raw hipError_t of the last FEP_EHIP on this thread */
 int         fep_device_count(int* n_out);
@@ -96,7 +99,10 @@ int fep_return_map_host(int device_id, int64_t n_int,
                         int accept,
                         double* s_h, double* ds_h, uint8_t* ind_p_h, int64_t* counts_h);
 
-/* Same on device-resident arrays.  `counts_d` (2 x int64, device) is zeroed and filled by the call. */
+/* Same on device-resident arrays.  `counts_d` (2 x int64, device) is zeroed and filled by the call.  With counts_d the
+ * call uses a per-(device, stream) scratch of 8 bytes per 256 points that grows on demand (FEP_ESTATE if it would have to
+ * grow while the stream is being captured: run the call once outside the capture first); a block handed out is never
+ * freed, so a HIP graph captured from this call stays valid for calls of up to the captured n_int. */
 int fep_return_map_dev(int device_id, void* stream, int64_t n_int,
                        const double* e_d, int64_t e_pt_stride, int64_t e_comp_stride,
                        const double* e0_h, double* ep_prev_d,
@@ -122,6 +128,10 @@ int fep_ctx_destroy(fep_ctx* ctx);
 
 /* sizes[0..7] = n_e, n_n, n_p, n_q, n_int, n_dof (=2*n_n), nnz (CSR entries of K), n_blk (node-pair blocks) */
 int fep_ctx_sizes(const fep_ctx* ctx, int64_t sizes[8]);
+/* The kernels one step of this context launches, named as rocprofv3 prints them and joined by " + " (which = 0: a step with
+ * every output, 1: the K,F-only step of a Newton iterate).  `buf` receives a NUL-terminated string of at most cap - 1
+ * characters.  No reference counterpart (measurement support: bench.py's roofline label). */
+int fep_ctx_kernel_names(const fep_ctx* ctx, int which, char* buf, int64_t cap);
 
 /* dphi1, dphi2: (n_p, n_int); weight: (n_int); det: (n_int) or NULL.       DP:530-546, 585 */
 int fep_ctx_geometry_host(fep_ctx* ctx, double* dphi1_h, double* dphi2_h, double* weight_h, double* det_h);
@@ -132,7 +142,7 @@ int fep_ctx_pattern_host(const fep_ctx* ctx, int32_t* indptr_h /* n_dof+1 */, in
 
 /* Per-point material parameters (n_int each): shear, bulk (DP:972-973), eta, c (DP:983-984).  When each of the four
  * arrays is constant over the mesh (the reference's demos) the kernels take the constants as arguments and do not
- * read the arrays; results are bitwise the same either way (FEP_NO_UNIFORM=1 in the environment disables it). */
+ * read the arrays; results are bitwise the same either way. */
 int fep_ctx_set_materials_host(fep_ctx* ctx, const double* shear_h, const double* bulk_h,
                                const double* eta_h, const double* c_h);
 /* Device pointers of the context's static per-point arrays (for the mesh-free entry points):
@@ -194,6 +204,12 @@ int fep_assemble_host(fep_ctx* ctx, const double* ds_h, const double* s_h,
 int fep_gather_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* idx_d, double* dst_d);
 int fep_scatter_f64(int device_id, void* stream, int64_t n, const double* src_d, const int32_t* src_idx_d,
                     const int32_t* dst_idx_d, double* dst_d);
+/* Neighbour-only form of the same exchange (sharding.py, exchange='p2p'): after the send / receive batch, interface DOF i
+ * (local DOF loc[i]) becomes 0 + c_0 + c_1 + ... over its holders in ascending rank order; contribution k of DOF i is
+ * src[ptr[i] + k] < 0 ? this rank's own f[loc[i]] : recv[src[ptr[i] + k]].  Replaces nothing in the reference (DP:1058
+ * is the quantity exchanged). */
+int fep_iface_sum_f64(int device_id, void* stream, int64_t n, const int32_t* loc_d, const int32_t* ptr_d,
+                      const int32_t* src_d, const double* recv_d, double* f_d);
 
 /* ---- callers of the hot path ----------------------------------------------------------------
  * transform (DP:760-816): integration-point values (n_int) -> nodal values (n_n), mean over the points of the
@@ -232,9 +248,9 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
  * matrix on the context's pattern — normally K_elast — and pushed level by level; the solver applies it as a V(2,2)
  * cycle in which level 0 is always the CURRENT tangent (k_data_d of the call) and the coarse operators stay those of the
  * reference matrix.  Smoother: degree-2 Chebyshev in D^-1 A on [lmax/20, lmax], lmax = 1.2 x the value the hierarchy's
- * omega encodes (omega = 4 / (3 * 1.05 * rho)); FEP_AMG_SMOOTHER=jacobi selects two damped block-Jacobi sweeps instead.
+ * omega encodes (omega = 4 / (3 * 1.05 * rho)).
  * The preconditioner reads single precision — K in the smoother's level-0 passes, the refreshed coarse operators
- * (FEP_AMG_FP32=0: double), the transfers, applied in node blocks (FEP_AMG_BLOCK_TRANSFERS=0: the CSR forms as pushed) —;
+ * and the transfers, applied in node blocks —;
  * CG's own product, its vectors and the Galerkin products are double precision.
  *
  *   fep_solver_amg_push_level   transfer level k -> k+1 (k = number of levels pushed so far; level 0 = the mesh DOFs):
@@ -248,10 +264,12 @@ int fep_solver_pcg_dev(fep_solver* solver, void* stream, const double* k_data_d,
  *                               coarse operators from ITS k_data_d — A_1 = R_0 K P_0, A_2 = R_1 A_1 P_1, ... with the
  *                               transfers as pushed, block-Jacobi inverses and the coarsest inverse recomputed — instead of
  *                               keeping those of the reference matrix (numeric products on patterns fixed here by the host;
- *                               the terms of every output entry are listed on the device, FEP_AMG_PLAN=host: by the host too:
+ *                               the terms of every output entry are listed on the device:
  *                               40 % fewer iterations on plastic tangents).  FEP_ERANGE: coarsest level > 256 DOFs (its inverse
- *                               is recomputed by one workgroup) or a product with more than 2^31 terms — the hierarchy is
- *                               left as pushed; an allocation failure drops it.
+ *                               is recomputed by one workgroup; checked first, the hierarchy is left as pushed) or a product
+ *                               whose pattern / term list exceeds 32-bit counts (found while the plans are built: the
+ *                               hierarchy is DROPPED, as after an allocation failure).  A caller that wants to go on with the
+ *                               reference operators pushes the levels again after FEP_ERANGE (solver.py: setup_amg does).
  *   fep_solver_amg_refresh_dev  the re-projection alone, stream-ordered (FEP_ESTATE unless enabled)
  *   fep_aggregate_host          greedy aggregation of a node graph in CSR (a neighbour list may repeat ids, in any order):
  *                               agg_out[i] in [0, *n_agg_out) */

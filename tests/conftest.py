@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def needs_ablation_build(fep):
+    """Skips unless the loaded library was built with -DFEP_ABLATION (`python fem-elastoplasticity_amd/build.py --ablation`,
+    then FEP_LIB_PATH=.../csrc/libfep_hip_abl.so): the tests that compare a kernel variant behind a measurement switch with
+    the product's form.  The product library has no such switches."""
+    if not fep.lib().fep_build_is_ablation():
+        pytest.skip('needs the -DFEP_ABLATION build of the library (FEP_LIB_PATH=.../libfep_hip_abl.so)')
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
 

@@ -95,15 +95,16 @@ def test_tsx_p1_driver_vs_reference_replay(fep):
     assert abs(h['displ'][-1] - (-0.0019794496707526746)) <= 1e-10 * 0.0019794496707526746     # SURVEY 8c pin
 
 
-@pytest.mark.parametrize('route', ['node', 'node_list', 'node2k', 'node_unpacked', 'coo'])
+@pytest.mark.parametrize('route', ['node', 'patch', 'coo'])
 def test_tsx_p1_mesh_one_step_on_every_table_variant(fep, monkeypatch, route):
     """The call that aborted in round 2's first GPU run (gpurun_out/r2a: tsx-tunnel P1 mesh, 476 nodes, unstructured, tiles
-    kept as strips, through fep_step_host; profiles/r03_ablation.md): one host-array step on that mesh on every table
-    variant of the P1 path — run lists, element / node LISTS ('node_list'), two kernels, unpacked descriptors, the element
-    route — with the plan replayed against the mesh first (FEP_VALIDATE_PLAN), checked against the oracle.  Once per
-    variant, no repetition."""
+    kept as strips, through fep_step_host; profiles/r03_ablation.md): one host-array step on that mesh on every route of
+    the P1 path the product ships — the node route (its run / list tables are chosen by the mesh) and the element route in
+    both forms — with the plan replayed against the mesh first (FEP_VALIDATE_PLAN), checked against the oracle.  Once per
+    route, no repetition.  (The table variants behind FEP_P1_PATH exist in the -DFEP_ABLATION build only.)"""
     from oracle import fep_oracle as orc
-    monkeypatch.setenv('FEP_P1_PATH', route)
+    if route != 'node':
+        monkeypatch.setenv('FEP_ROUTE', route)
     monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
     g = load_golden('tsx')
     elem, coord = g['elem'], g['coord']

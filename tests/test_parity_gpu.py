@@ -149,14 +149,14 @@ def test_elastic_setup_vs_reference_golden(fep, t):
 
 
 # ---- a1..a5 ---------------------------------------------------------------------------
-@pytest.fixture(params=['node', 'node2k', 'node_unpacked', 'node_list', 'node_direct', 'coo', 'coo_kc'])
+@pytest.fixture(params=['node', 'patch', 'coo'])
 def p1_route(request, monkeypatch):
-    """P1 routes: the node-centric fast path (default: one fused kernel per non-accepting step, two kernels otherwise;
-    'node2k' = always two kernels; the other node_* names switch off one table compression each) and the generic element
-    route ('coo': its default patch form, 'coo_kc': with the K_e round trip through HBM)."""
-    monkeypatch.setenv('FEP_P1_PATH', 'coo' if request.param == 'coo_kc' else request.param)
-    if request.param == 'coo_kc':
-        monkeypatch.setenv('FEP_GEN_PATH', 'coo')
+    """P1 routes: the node-centric fast path (default: one fused kernel per K,F-only step, two kernels otherwise) and, as
+    independent cross-checks, the element route every other type runs — FEP_ROUTE=patch: K_e summed in LDS, FEP_ROUTE=coo:
+    K_e through HBM.  (The measured-slower variants of the node route live in the -DFEP_ABLATION build only.)"""
+    if request.param != 'node':
+        monkeypatch.setenv('FEP_ROUTE', request.param)
+    monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
     return request.param
 
 
@@ -204,73 +204,22 @@ def test_p1_fused_step_is_bitwise_the_two_kernel_route(fep, monkeypatch, name):
     in HBM unless asked for).  Bit for bit the two-kernel route: K, F with and without the point outputs, s, ds, ind_p,
     strain, counters — structured and Delaunay meshes (run-compressed and list tables), per-point materials, e0."""
     elem, coord, mats, U, Ep, e0 = _p1_case(fep, name)
-    res = {}
-    for route in ('node', 'node2k'):
-        monkeypatch.setenv('FEP_P1_PATH', route)
-        ctx = fep.MeshContext(elem, coord)
-        ctx.set_materials(*mats)
-        ep = Ep.copy()
-        kw = {} if e0 is None else {'e0': e0}
-        full = ctx.step(U, ep, want=('E', 's', 'ds', 'ind_p', 'K', 'F'), **kw)
-        kf = ctx.step(U, ep, want=('K', 'F'), **kw)
-        k_only = ctx.step(U, ep, want=('K',), **kw)
-        f_only = ctx.step(U, None, want=('F',), **kw)
-        assert np.array_equal(ep, Ep)
-        res[route] = (full, kf, k_only, f_only)
-        ctx.close()
-    a, b = res['node'], res['node2k']
-    assert a[0]['n_smooth'] > 0 and a[0]['n_apex'] > 0
-    for x, y in zip(a, b):
-        assert (x['n_smooth'], x['n_apex']) == (y['n_smooth'], y['n_apex'])
-        for key in x:
-            if key == 'K':
-                assert np.array_equal(x['K'].data, y['K'].data), key
-            elif key not in ('n_smooth', 'n_apex'):
-                assert np.array_equal(x[key], y[key]), key
-    assert np.array_equal(a[0]['K'].data, a[1]['K'].data) and np.array_equal(a[0]['F'], a[1]['F'])
-    assert np.array_equal(a[0]['K'].data, a[2]['K'].data)
-
-
-@pytest.mark.parametrize('t,n', [('P2', 40), ('Q2', 30), ('Q1', 50)])
-def test_reduce_kernel_forms_are_bitwise_equal(fep, monkeypatch, t, n):
-    """COO route: the reduce kernel with packed block descriptors and four contribution addresses per load against the
-    round-1 form (segptr / meta / one address per load, 2 to 8 gathers in flight): same adds in the same order."""
-    mesh = fep.square_mesh(n, t, 10)
-    x, y = mesh['coordinates']
-    U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
-    res = []
-    monkeypatch.setenv('FEP_GEN_PATH', 'coo')
-    for env in ({}, {'FEP_CSR_UNPACKED': '1', 'FEP_CSR_GATHERS': '2'}, {'FEP_CSR_UNPACKED': '1', 'FEP_CSR_GATHERS': '8'}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
-        ctx.set_materials(*[v[0] for v in dp_materials(1)])
-        r = ctx.step(U, np.zeros((4, ctx.n_int)), want=('K', 'F'))
-        res.append((r['K'].data.copy(), r['F'].copy(), r['n_smooth'], r['n_apex']))
-        ctx.close()
-    assert res[0][2] > 0 and res[0][3] > 0
-    for other in res[1:]:
-        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and res[0][2:] == other[2:]
-
-
-def test_p1_assembly_from_staged_nodes_is_bitwise_the_record_form(fep, monkeypatch):
-    """FEP_P1_ASM=nodes: the assembly kernel takes its geometry from the tile's LDS-staged nodes instead of the 48-byte
-    records; same K, F bit for bit (full-output step, accepting step, assemble_tangent)."""
-    elem, coord, mats, U, Ep, e0 = _p1_case(fep, 'square150')
-    res = []
-    for mode in ('record', 'nodes'):
-        monkeypatch.setenv('FEP_P1_ASM', mode)
-        ctx = fep.MeshContext(elem, coord)
-        ctx.set_materials(*mats)
-        ep = Ep.copy()
-        full = ctx.step(U, ep, want=('s', 'ds', 'K', 'F'))
-        acc = ctx.step(U, ep, apply_plastic_strain=True, want=('K', 'F'))
-        K2, F2 = ctx.assemble(full['ds'], full['s'])
-        _, F3 = ctx.assemble(None, full['s'])
-        res.append((full['K'].data, full['F'], acc['K'].data, acc['F'], K2.data, F2, F3, full['n_smooth'], acc['n_apex']))
-        ctx.close()
-    for a, b in zip(*res):
-        assert np.array_equal(a, b)
+    ctx = fep.MeshContext(elem, coord)
+    ctx.set_materials(*mats)
+    ep = Ep.copy()
+    kw = {} if e0 is None else {'e0': e0}
+    full = ctx.step(U, ep, want=('E', 's', 'ds', 'ind_p', 'K', 'F'), **kw)        # point outputs wanted: two kernels
+    kf = ctx.step(U, ep, want=('K', 'F'), **kw)                                    # the one-kernel step
+    k_only = ctx.step(U, ep, want=('K',), **kw)
+    f_only = ctx.step(U, None, want=('F',), **kw)
+    f_zero_ep = ctx.step(U, np.zeros_like(Ep), want=('s', 'F'), **kw)              # two kernels, the state f_only ran on
+    assert np.array_equal(ep, Ep)
+    K2, F2 = ctx.assemble(full['ds'], full['s'])                                   # assembly kernel alone on the stored ds / s
+    ctx.close()
+    assert full['n_smooth'] > 0 and full['n_apex'] > 0
+    assert np.array_equal(full['K'].data, kf['K'].data) and np.array_equal(full['F'], kf['F'])
+    assert np.array_equal(full['K'].data, k_only['K'].data) and np.array_equal(f_only['F'], f_zero_ep['F'])
+    assert np.array_equal(K2.data, full['K'].data) and np.array_equal(F2, full['F'])
 
 
 def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
@@ -304,11 +253,12 @@ def test_p1_mesh_with_a_node_of_no_element(fep, p1_route):
     ctx.close()
 
 
-@pytest.fixture(params=['node', 'coo', 'patch'])
+@pytest.fixture(params=['patch', 'coo'])
 def gen_route(request, monkeypatch):
-    """P2 / Q1 / Q2 have three routes: the element route in its patch form (default, also what P4 uses: K_e stays in
-    LDS), the same with the K_e round trip through HBM ('coo') and the opt-in node route."""
-    monkeypatch.setenv('FEP_GEN_PATH', request.param)
+    """P2 / Q1 / Q2 (and P4): the element route in its patch form (default: K_e stays in LDS) and, as the independent
+    cross-check, with the K_e round trip through HBM (FEP_ROUTE=coo)."""
+    if request.param == 'coo':
+        monkeypatch.setenv('FEP_ROUTE', 'coo')
     monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
     return request.param
 
@@ -354,15 +304,10 @@ def test_patch_route_against_the_coo_route(fep, monkeypatch, name):
     U += rng.normal(0, 3e-6, size=U.shape)
     Ep = rng.normal(0, 5e-6, size=(4, n))
     monkeypatch.setenv('FEP_VALIDATE_PLAN', '1')
-    monkeypatch.setenv('FEP_P1_PATH', 'coo')
     res = {}
-    # P2 has patches of two sizes (28 elements on 256 threads, 56 on 512: the default)
-    routes = ('coo', 'patch') + (('patch256', 'patch512') if t == 'P2' else ())
+    routes = ('coo', 'patch')
     for route in routes:
-        monkeypatch.setenv('FEP_GEN_PATH', route[:5] if route.startswith('patch') else route)
-        monkeypatch.delenv('FEP_PATCH_TPB', raising=False)
-        if route[5:]:
-            monkeypatch.setenv('FEP_PATCH_TPB', route[5:])
+        monkeypatch.setenv('FEP_ROUTE', route)                                # (P1 too: its node route is not what is compared here)
         ctx = fep.MeshContext(elem, coord)
         ctx.set_materials(*dp_materials(n))
         F_poison = ctx.step(1e3 * U, None, want=('K', 'F'))                   # other values in the scratch buffers
@@ -565,23 +510,34 @@ def test_heterogeneous_materials_vs_oracle(fep, t, N):
     test_hot_path_mid_size_vs_oracle(fep, t, N, heterogeneous=True)
 
 
-def test_constant_materials_fast_path_is_bitwise_the_array_path(fep, monkeypatch):
+def test_constant_materials_fast_path_is_bitwise_the_array_path(fep):
+    """Materials constant over the mesh (the reference's demos) are passed to the kernels as scalars, the four arrays are not
+    read; any other set of arrays takes the array path.  Same values bit for bit: the second context differs from the first
+    in the cohesion of the LAST element's points only, so every other point, and every row / force entry of a node outside
+    that element, must come out identical."""
     mesh = fep.square_mesh(30, 'P2', 10)
-    n_int = mesh['elements'].shape[1] * 7
+    elem = mesh['elements']
+    n_int = elem.shape[1] * 7
     x, y = mesh['coordinates']
     U = np.array([2.0e-4 * y * (x / 10) + 1.0e-4 * x * (y > 5), -1.2e-4 * y * (x < 5) + 1.6e-4 * y * (x >= 5)])
     res = []
-    for off in (False, True):
-        if off:
-            monkeypatch.setenv('FEP_NO_UNIFORM', '1')
-        ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
-        ctx.set_materials(*dp_materials(n_int))
+    for perturbed in (False, True):
+        mats = [v.copy() for v in dp_materials(n_int)]
+        if perturbed:
+            mats[3][-7:] *= 1.5
+        ctx = fep.MeshContext(elem, mesh['coordinates'])
+        ctx.set_materials(*mats)
         res.append(ctx.step(U, np.zeros((4, n_int)), want=('s', 'ds', 'K', 'F')))
         ctx.close()
     assert res[0]['n_smooth'] > 0
-    for k in ('s', 'ds', 'F'):
-        assert np.array_equal(res[0][k], res[1][k])
-    assert np.array_equal(res[0]['K'].data, res[1]['K'].data)
+    for k in ('s', 'ds'):
+        assert np.array_equal(res[0][k][:, :-7], res[1][k][:, :-7])
+    outside = np.ones(mesh['coordinates'].shape[1], dtype=bool)
+    outside[elem[:, -1]] = False
+    rows = np.repeat(outside, 2)
+    assert np.array_equal(res[0]['F'][rows], res[1]['F'][rows])
+    K0, K1 = res[0]['K'].tocsr(), res[1]['K'].tocsr()
+    assert np.array_equal(K0[rows].data, K1[rows].data)
 
 
 # ---- full benchmark size: properties (the reference cannot run here: DP:714 needs n_apex^2 memory) ----

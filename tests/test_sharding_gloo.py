@@ -46,25 +46,35 @@ def _local_oracle(orc, elem, coord, U, d1, d2, wf):
     return K_t, F, cp
 
 
-def _worker(rank, world, port, q, t='P1', exchange='allreduce'):
+def _worker(rank, world, port, q, t='P1', exchange='allreduce', subgroup=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    os.environ['FEP_EXCHANGE'] = exchange
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.pop('FEP_EXCHANGE', None)
+    group = None
+    if subgroup:
+        # the partition lives on a sub-group that does not start at global rank 0: group rank g is global rank g + 1
+        dist.init_process_group('gloo', rank=rank, world_size=world + 1)
+        group = dist.new_group(list(range(1, world + 1)))
+        if rank == 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        rank -= 1
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from oracle import fep_oracle as orc
     fep, elem, coord, U, d1, d2, wf = _problem(t)
-    part = fep.Partition(elem, coord.shape[1], rank, world)
+    part = fep.Partition(elem, coord.shape[1], rank, world, exchange=exchange)
+    assert part.exchange == exchange and part.active and not part.gated
     K_r, F_r, _ = _local_oracle(orc, part.local_elements, coord[:, part.nodes], U[:, part.nodes], d1, d2, wf)
     F_partial = F_r.copy()
-    part.exchange_force_host(F_r)
+    part.exchange_force_host(F_r, group=group)
     # both forms of the exchange on the same partial sums: bit-identical where a node has two holders (a + b either way); with
     # more holders the all-reduce's association is the library's, the neighbour form's is by rank
     other = F_partial.copy()
-    os.environ['FEP_EXCHANGE'] = 'p2p' if exchange == 'allreduce' else 'allreduce'
-    part.exchange_force_host(other)
-    os.environ['FEP_EXCHANGE'] = exchange
+    part.exchange_force_host(other, group=group, mode='p2p' if exchange == 'allreduce' else 'allreduce')
     two = np.repeat(part.mult <= 2, 2)
     assert np.array_equal(other[two], F_r[two]) and np.abs(other - F_r).max() <= 1e-15 * max(np.abs(F_r).max(), 1e-300)
     assert set(part.neighbours) <= set(range(world)) - {rank} and all(d.size % 2 == 0 for d in part.neighbours.values())
@@ -73,12 +83,15 @@ def _worker(rank, world, port, q, t='P1', exchange='allreduce'):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('t,world,exchange', [('P1', 2, 'allreduce'), ('P1', 3, 'allreduce'), ('P2', 2, 'allreduce'),
-                                              ('P1', 2, 'p2p'), ('P1', 3, 'p2p'), ('P2', 2, 'p2p'), ('P1', 4, 'p2p')])
-def test_interface_force_allreduce_gloo(t, world, exchange):
+@pytest.mark.parametrize('t,world,exchange,subgroup', [('P1', 2, 'allreduce', False), ('P1', 3, 'allreduce', False),
+                                                       ('P2', 2, 'allreduce', False), ('P1', 2, 'p2p', False),
+                                                       ('P1', 3, 'p2p', False), ('P2', 2, 'p2p', False), ('P1', 4, 'p2p', False),
+                                                       ('P1', 3, 'p2p', True)])
+def test_interface_force_allreduce_gloo(t, world, exchange, subgroup):
     """P2 (BASELINE configs[4]'s element type): a cut through a P2 mesh shares one row of vertex + midside nodes
-    (2 nx + 1 nodes) when it falls between two cell rows.  exchange = 'p2p': the neighbour-only form (FEP_EXCHANGE=p2p: sends
-    and receives between the ranks on the two sides of a cut, contributions added in ascending rank order)."""
+    (2 nx + 1 nodes) when it falls between two cell rows.  exchange = 'p2p': the neighbour-only form (sends and receives
+    between the ranks on the two sides of a cut, contributions added in ascending rank order).  subgroup: the ranks of the
+    partition are a sub-group of the world that starts at global rank 1 (peers of the sends are global ranks)."""
     from oracle import fep_oracle as orc
     fep, elem, coord, U, d1, d2, wf = _problem(t)
     K_g, F_g, cp = _local_oracle(orc, elem, coord, U, d1, d2, wf)
@@ -86,7 +99,7 @@ def test_interface_force_allreduce_gloo(t, world, exchange):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, t, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, t, exchange, subgroup)) for r in range(world + int(subgroup))]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -117,3 +130,53 @@ def test_partition_single_rank_is_identity():
     assert part.n_iface == 0 and np.array_equal(part.nodes, np.arange(coord.shape[1]))
     assert np.array_equal(part.local_elements, elem)
     assert fep.element_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]
+
+
+def test_partition_maps_against_the_sorted_construction():
+    """The linear-time construction (flag arrays, neighbour candidates by node-id interval) gives the maps of the plain one:
+    np.unique of every rank's range, intersections of all pairs."""
+    fep, elem, coord, *_ = _problem('P2', 7, 9)
+    rng = np.random.default_rng(0)
+    for elements in (elem, elem[:, rng.permutation(elem.shape[1])]):       # structured ranges, and ranges scattered over the mesh
+        n_n, world = coord.shape[1], 4
+        ranges = fep.element_ranges(elements.shape[1], world)
+        sets = [np.unique(elements[:, lo:hi]) for lo, hi in ranges]
+        touch = np.zeros(n_n, dtype=int)
+        for s_ in sets:
+            touch[s_] += 1
+        iface = np.flatnonzero(touch > 1)
+        for r in range(world):
+            part = fep.Partition(elements, n_n, r, world)
+            assert np.array_equal(part.nodes, sets[r]) and np.array_equal(part.mult, touch[sets[r]])
+            assert np.array_equal(part.nodes[part.local_elements], elements[:, ranges[r][0]:ranges[r][1]])
+            assert part.n_iface == iface.size and np.array_equal(iface[part.iface_slot], part.nodes[part.iface_local])
+            for q in range(world):
+                shared = np.intersect1d(sets[r], sets[q]) if q != r else np.zeros(0, dtype=int)
+                if shared.size:
+                    assert np.array_equal(part.nodes[part.neighbours[q][::2] // 2], shared)
+                else:
+                    assert q not in part.neighbours
+            # contribution lists of the neighbour-only form: every interface DOF lists its holders once, in ascending rank order
+            cnt = np.diff(part.p2p_ptr)
+            assert np.array_equal(cnt, np.repeat(touch[part.nodes[part.iface_local]], 2))
+            assert (part.p2p_src >= -1).all() and (part.p2p_src < part.p2p_send_dofs.size).all()
+            assert np.array_equal(np.sort(part.p2p_src[part.p2p_src >= 0]), np.arange(part.p2p_send_dofs.size))
+
+
+def test_gate_small_meshes_stay_on_fewer_ranks():
+    """north_star: a collective only when the mesh is large enough (below ~1e5 elements one GPU)."""
+    fep, elem, coord, *_ = _problem('P1', 6, 12)                          # 144 elements
+    n_n = coord.shape[1]
+    with pytest.warns(UserWarning, match='rank'):
+        p0 = fep.Partition(elem, n_n, 0, 4, min_elements_per_rank=100)
+    assert p0.gated and p0.active and p0.active_world == 1 and p0.n_iface == 0 and (p0.lo, p0.hi) == (0, 144)
+    assert np.array_equal(p0.local_elements, elem) and not p0.neighbours
+    p3 = fep.Partition(elem, n_n, 3, 4, min_elements_per_rank=100)
+    assert p3.gated and not p3.active and p3.nodes.size == 0 and p3.local_elements.shape == (3, 0) and p3.n_iface == 0
+    F = np.zeros(0)
+    assert p3.exchange_force_host(F) is F and p3.exchange_force_host(F, mode='p2p') is F       # nothing to exchange, no collective
+    two = [fep.Partition(elem, n_n, r, 4, min_elements_per_rank=60) for r in range(4)]           # 144 // 60 = 2 ranks
+    assert [p.active for p in two] == [True, True, False, False] and two[0].n_iface == 7 and two[0].active_world == 2
+    assert sorted(two[0].neighbours) == [1] and sorted(two[1].neighbours) == [0]
+    full = fep.Partition(elem, n_n, 1, 4, min_elements_per_rank=36)
+    assert not full.gated and full.active_world == 4

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import scipy.sparse.linalg as sspl
 
-from conftest import dp_materials, relerr
+from conftest import needs_ablation_build, dp_materials, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -154,6 +154,7 @@ def test_refresh_terms_listed_on_the_device_are_the_host_plan(fep, et, n, monkey
     factor) — FEP_AMG_PLAN=host lists them with fep_host.h's product_plan (the builder the sanitizer driver replays against the
     triple loop) and uploads the index pairs.  Same terms in the same order: the refreshed operators and with them every
     iterate of the solve are bit-identical."""
+    needs_ablation_build(fep)
     mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
     K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
     b = rng.normal(size=ctx.n_dof)
@@ -176,6 +177,7 @@ def test_bottom_of_the_cycle_in_one_workgroup(fep, et, n, monkeypatch):
     """tail_kernel runs the last smoothed level and the coarsest solve under it in one launch; FEP_AMG_TAIL=0 keeps the eight
     launches it replaces.  The same operations (the block-Jacobi step's sums are associated differently): the same iteration
     counts, solutions to 1e-9, each form bit-reproducible."""
+    needs_ablation_build(fep)
     mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
     K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
     b = rng.normal(size=ctx.n_dof)
@@ -203,6 +205,7 @@ def test_block_transfers_are_the_csr_transfers_in_single_precision(fep, et, n, m
     restrict_block_kernel); FEP_AMG_BLOCK_TRANSFERS=0 keeps the double-precision CSR forms.  The same preconditioner up to seven
     digits of the transfers: the same iteration counts (+-2), the same solution, still symmetric (CG converges monotonically
     enough to meet 1e-11), run-to-run bit-identical."""
+    needs_ablation_build(fep)
     mesh, ctx, r, qf, rng = _problem(fep, et, n, True)
     K_el = ctx.step(np.zeros(ctx.n_dof), want=('K',))['K']
     b = rng.normal(size=ctx.n_dof)

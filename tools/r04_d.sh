@@ -1,0 +1,13 @@
+#!/bin/bash
+out=gpurun_out/r4d; mkdir -p $out
+export TMPDIR=/tmp
+python -c "import importlib,sys; sys.path.insert(0,'.'); print(importlib.import_module('fem-elastoplasticity_amd').build())"
+ABL=$PWD/fem-elastoplasticity_amd/csrc/libfep_hip_abl.so
+run() { echo "== $*" >> $out/elem_bench.log; env "${@:1:$#-1}" python tools/elem_bench.py ${!#} 2>&1 | grep -v amdgpu.ids >> $out/elem_bench.log; }
+for t in "P2 708 5" "Q2 708 5" "Q1 708 5" "P4 354 5"; do
+run FEP_LIB_PATH=$ABL FEP_PHASE_CLK=1 "$t"
+done
+run FEP_LIB_PATH=$ABL FEP_PHASE_CLK=1 FEP_PATCH_TPB=256 FEP_PATCH_JS=1 "P4 354 5"
+run FEP_LIB_PATH=$ABL FEP_PHASE_CLK=1 FEP_PATCH_TPB=256 FEP_PATCH_JS=1 "P2 708 5"
+run FEP_LIB_PATH=$ABL FEP_PHASE_CLK=1 "P2 708 5 bands kf"
+cat $out/elem_bench.log | cut -c1-600

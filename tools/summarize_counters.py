@@ -85,7 +85,8 @@ def main():
                    'kf_only_kernel': {k: hb[k] for k in hb if k.startswith('p1_fused_kernel')},
                    'note': 'full-output step = p1_point_kernel + p1_node_lds_kernel; 2*FETCH_SIZE + WRITE_SIZE (KiB) * 1024, '
                            'separate rocprofv3 --pmc passes of `python3 bench.py --steps 10 --no-cpu-baseline` (tools/prof.sh)',
-                   'elements_per_gpu': 1002528}, open(os.path.join(out, 'traffic_latest.json'), 'w'), indent=1)
+                   'elements_per_gpu': 1002528, 'element_type': 'P1', 'state': 'bands'},
+                  open(os.path.join(out, 'traffic_latest.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
