@@ -438,6 +438,10 @@ def run(args):
                        'exchange': exchange_report(shard_s, dt_s)}
         shard_s.sh.close()
 
+    if rank != 0:                                   # everything below describes and prints rank 0's line; no collective follows
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # what the library runs (FEP_ROUTE: unset = the product's default route; coo / patch = the element route's cross-check forms)
     env_route = os.environ.get('FEP_ROUTE', '')
     route = ('node' if not env_route else 'coo' if env_route == 'coo' else 'element') if et == 'P1' else 'element'

@@ -16,10 +16,12 @@
 
 using namespace fep;
 
-// workgroup shape of the 15-node element's patch form (decided by measurement, profiles/r04_ablation.md)
+// workgroup shape of the 15-node element's patch form: 16 elements on 256 threads.  The same 16 elements on 512 threads with
+// two lanes per (element, node) pair in phase 2 (ElemCfg: JS = 2; 116 instead of 240 VGPRs, twice the waves per CU) measured
+// 3-4 % slower in one session (0.931 against 0.899-0.900 ms, profiles/r04_ablation.md): kept in the ablation build
 #ifndef FEP_P4_TPB
-#define FEP_P4_TPB 512
-#define FEP_P4_JS 2
+#define FEP_P4_TPB 256
+#define FEP_P4_JS 1
 #endif
 
 thread_local int fep_g_last_hip = 0;
@@ -59,7 +61,6 @@ struct fep_ctx {
     uint4 *pt_fix = nullptr, *pt_ffix = nullptr;
     uint2* pt_fixT = nullptr;
     int64_t n_patch = 0;
-    int patch_slots[2] = {0, 0};                        // resident workgroups of the patch kernel (assembly-only / from U), asked once
 #ifdef FEP_ABLATION
     unsigned long long* phase_clk = nullptr;            // FEP_PHASE_CLK=1: phase stamps of the last element_kernel launch (reported at destroy)
 #endif
@@ -652,7 +653,11 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 EBOF(8, 9, 384, 2); EBOF(8, 9, 512, 1);
 #endif
                 break;
-            case FEP_P4: EBOF(15, 12, 256, 1); EBOF(15, 12, 512, 2); break;
+            case FEP_P4: EBOF(15, 12, 256, 1);
+#ifdef FEP_ABLATION
+                EBOF(15, 12, 512, 2);
+#endif
+                break;
         }
 #undef EBOF
         return 0;                                        // no such instantiation
@@ -692,6 +697,8 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 CK(upload(&c->pt_desc, P.pdesc.data(), (int64_t)P.pdesc.size()));
                 CK(upload(&c->pt_pel, P.pel.data(), (int64_t)P.pel.size()));
                 CK(upload(&c->pt_pnodes, P.pnodes.data(), (int64_t)P.pnodes.size()));
+                P.items.push_back(fep_host::U2{0u, 0u});                         // (one pad entry each: element_kernel reads its tables
+                P.fitems.push_back(fep_host::U2{0u, 0u});                        //  at clamped indices, also for a patch without items)
                 CK(upload(&c->pt_items, (const uint2*)P.items.data(), (int64_t)P.items.size()));
                 CK(upload(&c->pt_codes, P.codes.data(), (int64_t)P.codes.size()));
                 CK(upload(&c->pt_fitems, (const uint2*)P.fitems.data(), (int64_t)P.fitems.size()));
@@ -883,22 +890,13 @@ static int prof_mark(fep_ctx* c, hipStream_t st) {
     return FEP_OK;
 }
 
-// workgroups of `kernel` the whole chip keeps resident at once (CUs x occupancy): the grid of a persistent kernel
-static int resident_workgroups(const void* kernel, int tpb, size_t dyn_lds, int device, int* out) {
-    int per_cu = 0, cus = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, tpb, dyn_lds));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    *out = std::max(1, per_cu) * std::max(1, cus);
-    return FEP_OK;
-}
-
 template <int NP, int NQ, bool FROM_U>
 static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, double* ep, int accept,
                           double* eout, double* s, double* ds, uint8_t* indp, uint2* blk_counts,
                           double* Kc, double* fe) {
     // patch route: Kc / fe carry the caller's CSR values / force (phase 3 writes them, fixup_kernel the open rest)
     const PatchArgs pa{c->pt_desc, c->pt_pel, c->pt_pnodes, c->pt_items, c->pt_codes, c->pt_fitems, c->pt_fcodes, c->Pc, c->Pf,
-                       c->patch ? Kc : nullptr, c->patch ? fe : nullptr, c->n_patch
+                       c->patch ? Kc : nullptr, c->patch ? fe : nullptr
 #ifdef FEP_ABLATION
                        , c->phase_clk
 #endif
@@ -907,15 +905,8 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
 #define ELEM_LAUNCH_T(GEO, PATCH, TPB, JS)                                                                               \
     do {                                                                                                                 \
         if (c->patch_eb != 0 && c->patch_eb != ElemCfg<NP, NQ, GEO, TPB, JS>::EB) return FEP_ESTATE;                    \
-        /* patch form: ONE wave of resident workgroups, each walking patches g, g + G, ... (persistent, software-pipelined) */ \
-        unsigned grid = grid_for(c->n_e, ElemCfg<NP, NQ, GEO, TPB, JS>::EB);                                            \
-        if (PATCH) {                                                                                                     \
-            int& slots = c->patch_slots[FROM_U ? 1 : 0];                                                                 \
-            if (slots == 0) FEP_TRY(resident_workgroups((const void*)element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB, JS>, TPB, \
-                                                        (size_t)c->lds_pad, c->device, &slots));                        \
-            grid = (unsigned)std::min<int64_t>(c->n_patch, slots);                                                       \
-        }                                                                                                                \
-        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB, JS>), dim3(grid),                           \
+        hipLaunchKernelGGL((element_kernel<NP, NQ, FROM_U, GEO, PATCH, TPB, JS>),                                       \
+                           dim3(PATCH ? (unsigned)c->n_patch : grid_for(c->n_e, ElemCfg<NP, NQ, GEO, TPB, JS>::EB)),       \
                            dim3(TPB), (size_t)c->lds_pad, st, c->n_e,                                                   \
                            c->elem, c->dphi1, c->dphi2, c->weight, c->xy, c->dh1, c->dh2, c->wf, u, e0, ep, c->shear,   \
                            c->bulk, c->eta, c->c, c->matu, accept, eout, s, ds, indp, blk_counts,                       \
@@ -936,8 +927,8 @@ static int launch_element(fep_ctx* c, hipStream_t st, const double* u, E0 e0, do
     if (!c->patch) ELEM_GEO_BOTH(false, kBlock, 1);
     else if (shape == 256 * 8 + 1) ELEM_PATCH(256, 1);
     else if (NP == 6 && shape == 512 * 8 + 1) { if constexpr (NP == 6) ELEM_PATCH(512, 1); }
-    else if (NP == 15 && shape == 512 * 8 + 2) { if constexpr (NP == 15) ELEM_PATCH(512, 2); }
 #ifdef FEP_ABLATION
+    else if (NP == 15 && shape == 512 * 8 + 2) { if constexpr (NP == 15) ELEM_PATCH(512, 2); }
     else if (NP == 8 && shape == 512 * 8 + 1) { if constexpr (NP == 8) ELEM_PATCH(512, 1); }
     else if (NP == 8 && shape == 384 * 8 + 2) { if constexpr (NP == 8) ELEM_PATCH(384, 2); }
 #endif

@@ -375,7 +375,6 @@ struct PatchArgs {
     const uint2* fitems; const uint16_t* fcodes;
     double* Pc; double* Pf;                             // partial blocks (4 doubles per slot) / partial forces (2)
     double* data; double* F;                            // CSR values / nodal force (either may be NULL)
-    int64_t n_patch;                                    // the grid is one wave of resident workgroups: each takes patches g, g + G, ...
 #ifdef FEP_ABLATION
     unsigned long long* clk;                            // FEP_PHASE_CLK: 8 shader-clock stamps per workgroup (thread 0), or NULL
 #endif
@@ -388,19 +387,8 @@ struct PatchArgs {
 #define FEP_STAMP_P(pa, p, i) do { } while (0)
 #endif
 
-// Waves per SIMD the patch form is compiled for (register budget = 512 / waves): the LDS image admits this many.
-#ifndef FEP_PATCH_WAVES
-#define FEP_PATCH_WAVES(NP, TPB) ((NP) == 15 ? 2 : (NP) == 8 ? 3 : 4)
-#endif
-// PATCH form: a PERSISTENT, software-pipelined workgroup (round 4).  The grid is one wave of resident workgroups; workgroup g
-// takes the patches g, g + G, g + 2G, ...  A patch's inputs are fetched one iteration ahead: its element / node ids during the
-// iteration before the previous one's end, its node coordinates and displacements and its points' previous plastic strain
-// while the patch before it is in phases 1-3 — the two dependent global round trips of the staging step (ids -> node data;
-// 22 % of a workgroup's life in the one-patch-per-workgroup form, in-kernel clocks: profiles/r04_ablation.md) and the wait for
-// the plastic strain at the top of phase 1 no longer stand in anybody's way.  Same arithmetic in the same order: results are
-// bit-identical to the one-patch form.
 template <int NP, int NQ, bool FROM_U, bool GEO, bool PATCH = false, int TPB = kBlock, int JS = 1>
-__global__ void __launch_bounds__(TPB, PATCH ? FEP_PATCH_WAVES(NP, TPB) : 1)
+__global__ void __launch_bounds__(TPB, (NP == 15 && TPB == 512) ? 4 : 1)     // (15 nodes on 512 threads: <= 128 VGPRs, two workgroups per CU)
 element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
                const double* __restrict__ dphi1, const double* __restrict__ dphi2, const double* __restrict__ weight,
                // GEO: geometry recomputed from the coordinates (xy interleaved) and the reference-element tables
@@ -420,9 +408,8 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     constexpr int NJ = C::NJ;                        // stored node-pair blocks (a, a+j mod NP) per (element, local node)
     constexpr int NJH = C::NJH;                      // ... of which a lane of phase 2 computes NJH (all of them unless JS > 1)
     static_assert(PATCH || JS == 1, "the split of a node's blocks over JS lanes exists in the patch form only");
-    constexpr int kP12 = C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2);
-    constexpr int kImg = (PATCH && C::kPhase3 > kP12) ? C::kPhase3 : kP12;                  // phases 1-2 | phase 3, same memory
-    constexpr int kLds = kImg + (GEO ? C::kTab : 4);                                        // + the reference-element tables, kept for the kernel's life
+    constexpr int kP12 = C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2) + (GEO ? C::kTab : 4);
+    constexpr int kLds = (PATCH && C::kPhase3 > kP12) ? C::kPhase3 : kP12;                  // phases 1-2 | phase 3, same memory
     static_assert(EB * NQ <= TPB && EB * NP * JS <= TPB, "one pass per phase");
     __shared__ __attribute__((aligned(16))) double lds[kLds];
     double (*d1s)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds);
@@ -431,137 +418,53 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     double (*Ss)[NPTS] = reinterpret_cast<double (*)[NPTS]>(lds + (2 * NP + 6) * NPTS);
     double2 (*cxy)[EB] = reinterpret_cast<double2 (*)[EB]>(lds + C::kPts);                       // node coordinates per element
     double2 (*cu)[EB] = reinterpret_cast<double2 (*)[EB]>(lds + C::kPts + (GEO ? C::kXY : 2));   // node displacements
-    double* t1 = lds + kImg;
+    double* t1 = lds + C::kPts + (GEO ? C::kXY : 2) + (FROM_U ? C::kXY : 2);
     double* t2 = t1 + (GEO ? NP * NQ : 1);
     double* tw = t2 + (GEO ? NP * NQ : 1);
     uint32_t* codes32 = reinterpret_cast<uint32_t*>(lds + C::kKl + C::kFl);              // phase 3: behind the blocks and force pairs
     uint32_t* fcodes32 = reinterpret_cast<uint32_t*>(lds + C::kKl + C::kFl + C::kCodes);
-    __shared__ int32_t pel_s[PATCH ? 2 : 1][PATCH ? EB : 1];                             // element ids of the current / the next patch
 
-    const int64_t n_int_k = n_e * NQ;
-    const int64_t n_patch = PATCH ? pa.n_patch : 0, G = gridDim.x;
-    // The lane's indices are formed from an OPAQUE copy of the thread id, once in the prologue and again in every iteration of
-    // the patch loop: as loop invariants the compiler hoists every address derived from them out of the loop and keeps them
-    // in registers across it (210 instead of ~120 VGPRs, half the resident workgroups).
-#define FEP_LANE_INDICES(tid)                                                                                            \
-    int t = (tid);                                                                                                       \
-    asm volatile("" : "+v"(t));                                                                                          \
-    const int sa = t / EB, sel = t - sa * EB;          /* the lane's staging slot: (local node, element of the workgroup) */ \
-    const bool slot = (FROM_U || GEO) && t < NP * EB;                                                                    \
-    const int el1 = t / NQ, q1 = t - el1 * NQ          /* the lane's point in phase 1 */
-
-    if (GEO) {
-        for (int i = threadIdx.x; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
-        for (int i = threadIdx.x; i < NQ; i += TPB) tw[i] = wf[i];
-    }
-    // ---- prologue of the patch form: the first patch's inputs, and the ids of the second
-    int64_t p = blockIdx.x, pn = p + G;               // (patch indices: made scalar again at the top of every iteration, see there)
-    int32_t nd_n = 0, pel_n = -1;                      // NEXT patch: node id of the lane's staging slot, element id of slot t < EB
-    double2 xy_c = make_double2(0.0, 0.0), u_c = make_double2(0.0, 0.0);     // CURRENT patch: the slot's node data
-    double p_c[4] = {0.0, 0.0, 0.0, 0.0};              // CURRENT patch: the point's previous plastic strain
-    double m_c[4] = {0.0, 0.0, 0.0, 0.0};              // ... and its material parameters when they are per-point arrays
-    if (PATCH) {
-        FEP_LANE_INDICES(threadIdx.x);
-        const int64_t n_int = n_int_k;
-        int32_t nd_c = 0;
-        if (t < EB) pel_s[0][t] = pa.pel[p * EB + t];
-        if (slot) nd_c = pa.pnodes[(p * NP + sa) * EB + sel];
-        if (pn < n_patch) {
-            if (t < EB) pel_n = pa.pel[pn * EB + t];
-            if (slot) nd_n = pa.pnodes[(pn * NP + sa) * EB + sel];
-        }
-        if (slot && GEO) xy_c = *reinterpret_cast<const double2*>(xy + 2 * (int64_t)nd_c);
-        if (slot && FROM_U) u_c = *reinterpret_cast<const double2*>(U + 2 * (int64_t)nd_c);
-        __syncthreads();                               // pel_s[0]
-        if (FROM_U && ep && t < EB * NQ) {
-            const int32_t e = pel_s[0][el1];
-            if (e >= 0) {
-                const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
-                p_c[0] = ld_row(ep, n_int, 0, kb); p_c[1] = ld_row(ep, n_int, 1, kb); p_c[2] = ld_row(ep, n_int, 2, kb); p_c[3] = ld_row(ep, n_int, 3, kb);
-            }
-        }
-        if (FROM_U && !mu.on && t < EB * NQ) {
-            const int32_t e = pel_s[0][el1];
-            if (e >= 0) {
-                const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
-                m_c[0] = ld_row(shear, 0, 0, kb); m_c[1] = ld_row(bulk, 0, 0, kb); m_c[2] = ld_row(eta, 0, 0, kb); m_c[3] = ld_row(cc, 0, 0, kb);
-            }
-        }
-        asm volatile("" : "+v"(m_c[0]), "+v"(m_c[1]), "+v"(m_c[2]), "+v"(m_c[3]));
-        // (landed before the loop is entered, as the prefetches inside it are in front of phase 3: see there)
-        asm volatile("" : "+v"(xy_c.x), "+v"(xy_c.y), "+v"(u_c.x), "+v"(u_c.y));
-        asm volatile("" : "+v"(p_c[0]), "+v"(p_c[1]), "+v"(p_c[2]), "+v"(p_c[3]));
-        asm volatile("" : "+v"(nd_n), "+v"(pel_n));
-    }
-
-    for (int it = 0; PATCH ? p < n_patch : it < 1; ++it) {
-    FEP_LANE_INDICES(threadIdx.x);
-    // (the row stride likewise: the row bases of ld_row / st_row are scalar registers, and as loop invariants two dozen of
-    // them stay allocated across the loop — past the scalar file they spill into vector registers)
-    int64_t n_int = n_int_k;
-    asm volatile("" : "+s"(n_int));
-    // the loop-carried patch indices are uniform, which the compiler no longer sees: without this the descriptor below is a
-    // VECTOR load and its wait (vmcnt(0)) at the top of every iteration drains the stores of the patch before
-    p = (int64_t)__builtin_amdgcn_readfirstlane((int)p);
-    pn = (int64_t)__builtin_amdgcn_readfirstlane((int)pn);
-    const int cb = it & 1;                             // pel_s buffer of the current patch
-    const int64_t e0blk = (int64_t)blockIdx.x * EB;    // COO form: the workgroup's elements are e0blk .. e0blk + nel - 1
+    const int t = threadIdx.x;
+    const int64_t e0blk = (int64_t)blockIdx.x * EB;     // COO form: the workgroup's elements are e0blk .. e0blk + nel - 1
+    const int64_t n_int = n_e * NQ;
     // patch form: the elements are listed in pel (any ids, ascending); pdesc: 8 ints per patch (uniform address: scalar loads)
-    // (an explicit SCALAR load: inside the loop, behind the stores of the patch before, the compiler no longer proves the table
-    // read-only and falls back to a vector load whose wait — vmcnt(0) — would drain those stores at the top of every iteration)
-    typedef int v8i __attribute__((ext_vector_type(8)));
-    v8i pdv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (PATCH) {
-        const int32_t* pd = pa.pdesc + p * 8;
-        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pdv) : "s"(pd) : "memory");
-    }
-    const int item_off = pdv[0], n_items = pdv[1], code_off = pdv[2], n_codes = pdv[3];
-    const int fitem_off = pdv[4], n_fitems = pdv[5], fcode_off = pdv[6], n_fcodes = pdv[7];
+    const int32_t* pd = PATCH ? pa.pdesc + (int64_t)blockIdx.x * 8 : nullptr;
+    const int item_off = PATCH ? pd[0] : 0, n_items = PATCH ? pd[1] : 0, code_off = PATCH ? pd[2] : 0, n_codes = PATCH ? pd[3] : 0;
+    const int fitem_off = PATCH ? pd[4] : 0, n_fitems = PATCH ? pd[5] : 0, fcode_off = PATCH ? pd[6] : 0, n_fcodes = PATCH ? pd[7] : 0;
     const int nel = PATCH ? n_fcodes / NP : (int)((n_e - e0blk) < EB ? (n_e - e0blk) : EB);
-    const bool has_n = PATCH && pn < n_patch;
-    const int64_t pnn = pn + G;
 
-    FEP_STAMP_P(pa, p, 0);
-    // ---- staging: the current patch's node data from the registers the iteration before filled; the next patch's gathers and
-    // the ids of the one after it go out here and come back under phases 1-3
-    double2 xy_n = make_double2(0.0, 0.0), u_n = make_double2(0.0, 0.0);
-    int32_t nd_nn = 0, pel_nn = -1;
-    if (PATCH) {
-        if (slot) {
-            if (GEO) cxy[sa][sel] = xy_c;
-            if (FROM_U) cu[sa][sel] = u_c;
+    FEP_STAMP_P(pa, blockIdx.x, 0);
+    __shared__ int32_t pel_s[PATCH ? EB : 1];
+    if (PATCH && t < EB) pel_s[t] = pa.pel[(int64_t)blockIdx.x * EB + t];
+    if (FROM_U || GEO) {
+        if (t < NP * EB) {
+            const int a = t / EB, el = t - a * EB;
+            const int64_t nd = PATCH ? pa.pnodes[((int64_t)blockIdx.x * NP + a) * EB + el]
+                                     : (el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0);
+            if (GEO) cxy[a][el] = *reinterpret_cast<const double2*>(xy + 2 * nd);
+            if (FROM_U) cu[a][el] = *reinterpret_cast<const double2*>(U + 2 * nd);
         }
-        if (t < EB) pel_s[cb ^ 1][t] = pel_n;
-        if (has_n && slot) {
-            if (GEO) xy_n = *reinterpret_cast<const double2*>(xy + 2 * (int64_t)nd_n);
-            if (FROM_U) u_n = *reinterpret_cast<const double2*>(U + 2 * (int64_t)nd_n);
+        if (GEO) {
+            for (int i = t; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+            for (int i = t; i < NQ; i += TPB) tw[i] = wf[i];
         }
-        if (pnn < n_patch) {
-            if (t < EB) pel_nn = pa.pel[pnn * EB + t];
-            if (slot) nd_nn = pa.pnodes[(pnn * NP + sa) * EB + sel];
-        }
-    } else if (slot) {
-        const int64_t nd = sel < nel ? elem[(int64_t)sa * n_e + e0blk + sel] : 0;
-        if (GEO) cxy[sa][sel] = *reinterpret_cast<const double2*>(xy + 2 * nd);
-        if (FROM_U) cu[sa][sel] = *reinterpret_cast<const double2*>(U + 2 * nd);
     }
-    if (PATCH) lds_barrier(); else if (FROM_U || GEO) __syncthreads();     // (patch form: nothing of this phase came from global memory)
-    FEP_STAMP_P(pa, p, 1);                                             // node data staged
+    if (FROM_U || GEO || PATCH) __syncthreads();
+    FEP_STAMP_P(pa, blockIdx.x, 1);                                                  // node data staged
 
-    // ---- phase 1 (one pass: EB * NQ <= TPB).  COO form: the point's operand loads are issued here, after the barrier: hoisting
-    // them in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
+    // ---- phase 1 (one pass: EB * NQ <= TPB).  The point's operand loads are issued here, after the barrier: hoisting
+    // them (and the patch tables) in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
     int branch = 0;
-    double p_n[4] = {0.0, 0.0, 0.0, 0.0};              // NEXT patch: the point's previous plastic strain
-    double m_n[4] = {0.0, 0.0, 0.0, 0.0};              // ... and its material parameters (arrays only)
+    const int el1 = t / NQ, q1 = t - el1 * NQ;
     if (t < EB * NQ && el1 < nel) {
         const int el = el1, q = q1;
-        const int64_t k = PATCH ? (int64_t)pel_s[cb][el] * NQ + q : e0blk * NQ + t;
+        const int64_t k = PATCH ? (int64_t)pel_s[el] * NQ + q : e0blk * NQ + t;
         const unsigned k32 = (unsigned)k, kb = k32 * 8u;             // byte offset of the point in a row (ld_row / st_row)
         const int li = el * NQS + q;
         double w;
         double ev[3] = {0.0, 0.0, 0.0};
         // Nodes in chunks of CH: gradients -> LDS image + strain sums (DP:1043).  All NP at once is 4*NP registers of
-        // loads in flight per lane; the 15-node element takes 5 at a time.
+        // loads in flight per lane; the 15-node element takes 5 at a time (its 512-thread form must stay within 128 VGPRs).
         // The strain is written out in fused multiply-adds: which of two products the compiler fuses is its choice, and it
         // chose differently in the 256- and the 512-thread instantiation (point outputs differed in the last bit).
         constexpr int CH = NP == 15 ? 5 : NP;
@@ -603,23 +506,15 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         }
         double s[4], d[6];
         if (FROM_U) {
-            double pp[4] = {0.0, 0.0, 0.0, 0.0};
-            if (ep) {
-                if (PATCH) { pp[0] = p_c[0]; pp[1] = p_c[1]; pp[2] = p_c[2]; pp[3] = p_c[3]; }
-                else { pp[0] = ld_row(ep, n_int, 0, kb); pp[1] = ld_row(ep, n_int, 1, kb); pp[2] = ld_row(ep, n_int, 2, kb); pp[3] = ld_row(ep, n_int, 3, kb); }
-            }
-            double m_sh, m_bu, m_eta, m_cc;
-            if (PATCH) {                                 // (patch form: per-point material arrays were fetched with the plastic strain)
-                m_sh = mu.on ? mu.shear : m_c[0]; m_bu = mu.on ? mu.bulk : m_c[1]; m_eta = mu.on ? mu.eta : m_c[2]; m_cc = mu.on ? mu.c : m_c[3];
-            } else {
-                m_sh = mu.on ? mu.shear : ld_row(shear, 0, 0, kb); m_bu = mu.on ? mu.bulk : ld_row(bulk, 0, 0, kb);
-                m_eta = mu.on ? mu.eta : ld_row(eta, 0, 0, kb); m_cc = mu.on ? mu.c : ld_row(cc, 0, 0, kb);
-            }
-            branch = dp_return_map(ev, e0.v, pp, m_sh, m_bu, m_eta, m_cc, accept != 0, s, d);
+            double p[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ep) { p[0] = ld_row(ep, n_int, 0, kb); p[1] = ld_row(ep, n_int, 1, kb); p[2] = ld_row(ep, n_int, 2, kb); p[3] = ld_row(ep, n_int, 3, kb); }
+            const double m_sh = mu.on ? mu.shear : ld_row(shear, 0, 0, kb), m_bu = mu.on ? mu.bulk : ld_row(bulk, 0, 0, kb);
+            const double m_eta = mu.on ? mu.eta : ld_row(eta, 0, 0, kb), m_c = mu.on ? mu.c : ld_row(cc, 0, 0, kb);
+            branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, accept != 0, s, d);
             store_point_off(kb, k32, n_int, s, d, branch, S, DS, indp);
             if (Eout) { st_row(Eout, n_int, 0, kb, ev[0]); st_row(Eout, n_int, 1, kb, ev[1]); st_row(Eout, n_int, 2, kb, ev[2]); }
             if (accept && ep && branch) {
-                st_row(ep, n_int, 0, kb, pp[0]); st_row(ep, n_int, 1, kb, pp[1]); st_row(ep, n_int, 2, kb, pp[2]); st_row(ep, n_int, 3, kb, pp[3]);
+                st_row(ep, n_int, 0, kb, p[0]); st_row(ep, n_int, 1, kb, p[1]); st_row(ep, n_int, 2, kb, p[2]); st_row(ep, n_int, 3, kb, p[3]);
             }
         } else {
             if (DS) {
@@ -632,49 +527,9 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         for (int m = 0; m < 6; ++m) Ds[m][li] = w * d[m];                        // vD = w*ds, DP:1047
         Ss[0][li] = w * s[0]; Ss[1][li] = w * s[1]; Ss[2][li] = w * s[2];        // DP:1058
     }
-    // the next patch's plastic strain: on its way while this patch is in phases 2-3 (its points belong to other elements than
-    // this patch's: an accepting call's stores above cannot reach them)
-    if (PATCH && FROM_U && ep && has_n && t < EB * NQ) {
-        const int32_t e = pel_s[cb ^ 1][el1];
-        if (e >= 0) {
-            const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
-            p_n[0] = ld_row(ep, n_int, 0, kb); p_n[1] = ld_row(ep, n_int, 1, kb); p_n[2] = ld_row(ep, n_int, 2, kb); p_n[3] = ld_row(ep, n_int, 3, kb);
-        }
-    }
-    if (PATCH && FROM_U && !mu.on && has_n && t < EB * NQ) {
-        const int32_t e = pel_s[cb ^ 1][el1];
-        if (e >= 0) {
-            const unsigned kb = ((unsigned)e * NQ + q1) * 8u;
-            m_n[0] = ld_row(shear, 0, 0, kb); m_n[1] = ld_row(bulk, 0, 0, kb); m_n[2] = ld_row(eta, 0, 0, kb); m_n[3] = ld_row(cc, 0, 0, kb);
-        }
-    }
-    if (FROM_U) count_branches(branch, nullptr, blk_counts ? blk_counts + (PATCH ? p - blockIdx.x : 0) : nullptr);
-    // phase 3's tables: the lane's first items and its share of the gather codes are fetched HERE, in front of phase 2, whose
-    // arithmetic they come back under
-    // EVERY item descriptor of the patch (at most NP*NP*EB of them): phase 3 then issues no load between its stores — a load
-    // there is waited for with everything older than it, i.e. with the stores of the round before
-    constexpr int MAXIT = (NP * NP * EB + TPB - 1) / TPB, FIT = (NP * EB + TPB - 1) / TPB;
-    constexpr int IT = 4;                               // items a lane advances together (independent LDS chains)
-    constexpr int NG = (MAXIT + IT - 1) / IT;
-    const uint2* its = pa.items + item_off;
-    uint2 dsc[NG * IT], fdsc[FIT];
-    constexpr int CWPT = (NP * NP * EB / 2 + TPB) / TPB, FWPT = (NP * EB / 2 + TPB) / TPB;
-    uint32_t cpre[CWPT], fpre[FWPT];
-    if (PATCH) {
-#pragma unroll
-        for (int u = 0; u < NG * IT; ++u) { const int i = u * TPB + t; dsc[u] = (pa.data && u < MAXIT && i < n_items) ? its[i] : make_uint2(0u, 0u); }
-#pragma unroll
-        for (int u = 0; u < FIT; ++u) { const int i = u * TPB + t; fdsc[u] = (pa.F && i < n_fitems) ? pa.fitems[fitem_off + i] : make_uint2(0u, 0u); }
-        // two codes per 32-bit word (every patch's codes start at an even offset; one pad entry may be read)
-        const uint32_t* cg = reinterpret_cast<const uint32_t*>(pa.codes + code_off);
-        const uint32_t* fg = reinterpret_cast<const uint32_t*>(pa.fcodes + fcode_off);
-#pragma unroll
-        for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; cpre[r] = (pa.data && i < (n_codes + 1) / 2) ? cg[i] : 0u; }
-#pragma unroll
-        for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; fpre[r] = (pa.F && i < (n_fcodes + 1) / 2) ? fg[i] : 0u; }
-    }
+    if (FROM_U) count_branches(branch, nullptr, blk_counts);
     lds_barrier();                                                     // (the point outputs' stores drain behind phase 2)
-    FEP_STAMP_P(pa, p, 2);                                             // phase 1 done
+    FEP_STAMP_P(pa, blockIdx.x, 2);                                                  // phase 1 done
 
     // ---- phase 2 (one pass: NP * EB * JS <= TPB) ----------------------------------
     // lane (h, a, el): the blocks j = h*NJH .. of the (element, node) pair; h = 0 also sums the force pair
@@ -754,9 +609,50 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     double2* fl2 = reinterpret_cast<double2*>(lds + C::kKl);           // force pair (a, el) at [a * EB + el]
     const uint16_t* codes_l = reinterpret_cast<const uint16_t*>(codes32);
     const uint16_t* fcodes_l = reinterpret_cast<const uint16_t*>(fcodes32);
-    FEP_STAMP_P(pa, p, 3);                                             // phase 2 done (thread 0's wave)
+    // Phase 3's tables, fetched behind phase 2 — EVERY item descriptor of the patch (at most NP*NP*EB of them), so that phase 3
+    // issues no load between its stores: a load there is waited for with everything older than it (vmcnt counts in order),
+    // i.e. with the stores of the round before — the 15-node element has four such rounds.  Not in FRONT of phase 2: the
+    // vector-memory queue is in order too, and loads issued right behind phase 1's burst of point-output stores stall at
+    // issue until those have drained (measured: phase 1 11.7 k -> 20.3 k clocks for P2, step +14 %, profiles/r04_ablation.md)
+    constexpr int MAXIT = (NP * NP * EB + TPB - 1) / TPB, FIT = (NP * EB + TPB - 1) / TPB;
+    constexpr int IT = 4;                               // items a lane advances together (independent LDS chains)
+    constexpr int NG = (MAXIT + IT - 1) / IT;
+    const uint2* its = pa.items + item_off;
+    uint2 dsc[NG * IT], fdsc[FIT];
+    constexpr int CWPT = (NP * NP * EB / 2 + TPB) / TPB, FWPT = (NP * EB / 2 + TPB) / TPB;
+    uint32_t cpre[CWPT], fpre[FWPT];
+    if (PATCH) {
+        // UNCONDITIONAL loads at clamped indices (the tables are padded by one entry; a lane past the end re-reads the last
+        // item and never uses it): a load under a per-lane condition is waited for on the spot — fifteen of them for the
+        // 15-node element were fifteen round trips in a row (phase-clock: 20 k of the workgroup's 58 k cycles)
+#pragma unroll
+        for (int u = 0; u < NG * IT; ++u) dsc[u] = make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < FIT; ++u) fdsc[u] = make_uint2(0u, 0u);
+#pragma unroll
+        for (int r = 0; r < CWPT; ++r) cpre[r] = 0u;
+#pragma unroll
+        for (int r = 0; r < FWPT; ++r) fpre[r] = 0u;
+        if (pa.data) {                                  // (uniform)
+            const int last = n_items > 0 ? n_items - 1 : 0, lastc = n_codes > 0 ? (n_codes - 1) / 2 : 0;
+            const uint32_t* cg = reinterpret_cast<const uint32_t*>(pa.codes + code_off);     // two codes per 32-bit word (every
+#pragma unroll                                                                               // patch's codes start at an even offset)
+            for (int u = 0; u < MAXIT; ++u) { const int i = u * TPB + t; dsc[u] = its[i < last ? i : last]; }
+#pragma unroll
+            for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; cpre[r] = cg[i < lastc ? i : lastc]; }
+        }
+        if (pa.F) {
+            const int last = n_fitems > 0 ? n_fitems - 1 : 0, lastc = n_fcodes > 0 ? (n_fcodes - 1) / 2 : 0;
+            const uint32_t* fg = reinterpret_cast<const uint32_t*>(pa.fcodes + fcode_off);
+#pragma unroll
+            for (int u = 0; u < FIT; ++u) { const int i = u * TPB + t; fdsc[u] = pa.fitems[fitem_off + (i < last ? i : last)]; }
+#pragma unroll
+            for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; fpre[r] = fg[i < lastc ? i : lastc]; }
+        }
+    }
+    FEP_STAMP_P(pa, blockIdx.x, 3);                                                  // phase 2 done (thread 0's wave)
     lds_barrier();                                                     // every lane is done reading the phase-2 operands
-    FEP_STAMP_P(pa, p, 4);
+    FEP_STAMP_P(pa, blockIdx.x, 4);
     if (lane2) {
 #pragma unroll
         for (int j = 0; j < NJH; ++j) {
@@ -774,16 +670,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 #pragma unroll
     for (int r = 0; r < FWPT; ++r) { const int i = r * TPB + t; if (i < (n_fcodes + 1) / 2) fcodes32[i] = fpre[r]; }
     lds_barrier();
-    FEP_STAMP_P(pa, p, 5);                                             // K_e image and codes in LDS
-    // The next patch's prefetched values LAND here, in front of this patch's stores: a first use in the next iteration would
-    // make the compiler wait for every memory operation of this one (its count across the back edge is conservative:
-    // vmcnt(0)), i.e. for the stores below to drain.  Here the loads are one to two phases old.
-    if (PATCH) {
-        asm volatile("" : "+v"(xy_n.x), "+v"(xy_n.y), "+v"(u_n.x), "+v"(u_n.y));
-        asm volatile("" : "+v"(p_n[0]), "+v"(p_n[1]), "+v"(p_n[2]), "+v"(p_n[3]));
-        asm volatile("" : "+v"(m_n[0]), "+v"(m_n[1]), "+v"(m_n[2]), "+v"(m_n[3]));
-        asm volatile("" : "+v"(nd_nn), "+v"(pel_nn));
-    }
+    FEP_STAMP_P(pa, blockIdx.x, 5);                                                  // K_e image and codes in LDS
     if (pa.data) {
         double2* data2 = reinterpret_cast<double2*>(pa.data);
         double2* Pc2 = reinterpret_cast<double2*>(pa.Pc);
@@ -847,16 +734,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             if (d.x >> 31) Pf2[d.y] = make_double2(g0, g1); else F2[d.y] = make_double2(g0, g1);
         }
     }
-    FEP_STAMP_P(pa, p, 6);                                             // thread 0's wave has issued its last store
-    // ---- next patch: what was fetched under this one becomes current; the image must have been read before it is overwritten
-    lds_barrier();
-    xy_c = xy_n; u_c = u_n;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { p_c[m] = p_n[m]; m_c[m] = m_n[m]; }
-    nd_n = nd_nn; pel_n = pel_nn;
-    p = pn; pn = pnn;
-    }
-#undef FEP_LANE_INDICES
+    FEP_STAMP_P(pa, blockIdx.x, 6);                                                  // thread 0's wave has issued its last store
 }
 
 // Second kernel of the patch route: one lane per UPPER open block (a node pair on a patch boundary, row node <= column
@@ -878,13 +756,16 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, const uint
         const int cnt = (int)(f.y >> 16), deg = (int)(f.y & 0xffffu);
         const double2* P2 = reinterpret_cast<const double2*>(Pc);
         double a00, a01, a10, a11;
+        const uint2 ft = fixT[i];                                      // (issued with the partials, not behind them)
         if (cnt <= 2) {
-            const double2 p0 = P2[2 * (int64_t)f.z], p1 = P2[2 * (int64_t)f.z + 1];
+            // both partials go out together: with the second one under `cnt == 2` its load was issued only after the first
+            // had been waited for — three dependent levels (descriptor, first partial, second partial) instead of two.  A
+            // block with one contributor re-reads its first partial and drops it.
+            const int64_t z = (int64_t)f.z, w = cnt == 2 ? (int64_t)f.w : (int64_t)f.z;
+            const double2 p0 = P2[2 * z], p1 = P2[2 * z + 1];
+            const double2 q0 = P2[2 * w], q1 = P2[2 * w + 1];
             a00 = 0.0 + p0.x; a01 = 0.0 + p0.y; a10 = 0.0 + p1.x; a11 = 0.0 + p1.y;
-            if (cnt == 2) {
-                const double2 q0 = P2[2 * (int64_t)f.w], q1 = P2[2 * (int64_t)f.w + 1];
-                a00 += q0.x; a01 += q0.y; a10 += q1.x; a11 += q1.y;
-            }
+            if (cnt == 2) { a00 += q0.x; a01 += q0.y; a10 += q1.x; a11 += q1.y; }
         } else {
             a00 = a01 = a10 = a11 = 0.0;
             for (int k = 0; k < cnt; ++k) {
@@ -893,7 +774,6 @@ fixup_kernel(int nb_k, int64_t n_open, const uint4* __restrict__ fix, const uint
                 a00 += p0.x; a01 += p0.y; a10 += p1.x; a11 += p1.y;
             }
         }
-        const uint2 ft = fixT[i];
         double2* data2 = reinterpret_cast<double2*>(data);
         data2[f.x] = make_double2(a00, a01);
         data2[(int64_t)f.x + deg] = make_double2(a10, a11);

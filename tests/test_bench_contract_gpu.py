@@ -60,14 +60,37 @@ def test_single_gpu_line_p2():
 def test_two_ranks_started_by_bench_itself(scaling, et, cells):
     """('strong', 'P2'): the documented configs[4] command at a small size — `--gpus 2 --elem P2 --cells 48 --scaling strong`."""
     j = _run(['--gpus', '2', '--backend', 'gloo', '--elem', et, '--cells', str(cells), '--steps', '3', '--warmup', '1',
-              '--scaling', scaling], env={'FEP_BENCH_SINGLE_DEVICE': '1'})
+              '--scaling', scaling, '--min-elements-per-rank', '0'], env={'FEP_BENCH_SINGLE_DEVICE': '1'})
     assert KEYS <= set(j) and j['n_gpus'] == 2 and j['scaling'] == scaling and 'cpu_baseline' not in j
     n_e = 2 * cells * cells
     nq = {'P1': 1, 'P2': 7}[et]
     assert j['config']['elements_total'] == (n_e if scaling == 'strong' else 2 * n_e) and j['config']['element_type'] == et
     assert j['config']['points_total'] == nq * j['config']['elements_total']
-    assert len(j['per_rank']) == 2 and j['exchange_ms'] > 0
+    assert len(j['per_rank']) == 2 and j['active_ranks'] == 2
+    # BOTH forms of the interface exchange are timed in the same run; the headline names the one it used (VERDICT r3 item 4a)
+    x = j['exchange']
+    assert x['headline'] == 'allreduce' and j['exchange_ms'] == x['alone_ms']
+    assert x['alone_ms']['allreduce'] > 0 and x['alone_ms']['p2p'] > 0
+    assert set(x['step_ms']) == {'allreduce', 'p2p', 'none'} and min(x['step_ms'].values()) > 0
+    assert abs(x['step_ms']['allreduce'] - j['ms_per_step']) < 1e-9
+    for m in ('allreduce', 'p2p'):
+        assert x['exposed_ms'][m] >= 0 and x['hidden_ms'][m] >= 0 and x['bytes_per_rank'][m] > 0
+    assert x['bytes_per_rank']['p2p'] <= x['bytes_per_rank']['allreduce']      # one cut: the same nodes, 8 instead of 16 bytes per DOF slot
     assert ('strong' in j) == (scaling == 'weak')
     if scaling == 'weak':
-        assert j['strong']['elements_total'] == nq * n_e and sum(r['points'] for r in j['strong']['per_rank']) == nq * n_e
+        assert j['strong']['points_total'] == nq * n_e and j['strong']['elements_total'] == n_e
+        assert sum(r['points'] for r in j['strong']['per_rank']) == nq * n_e and j['strong']['exchange']['alone_ms']['p2p'] > 0
     assert abs(j['value'] - j['config']['points_total'] * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']
+
+
+def test_small_mesh_stays_on_one_rank():
+    """north_star: the collective only when the mesh is large enough — with the default gate (100 000 elements per rank) an
+    18 432-element square started on two ranks runs on ONE: rank 1 holds no context, no interface, nothing is exchanged, and
+    the line says so."""
+    j = _run(['--gpus', '2', '--backend', 'gloo', '--cells', '96', '--steps', '3', '--warmup', '1', '--scaling', 'strong'],
+             env={'FEP_BENCH_SINGLE_DEVICE': '1'})
+    n = 2 * 96 * 96
+    assert j['n_gpus'] == 2 and j['active_ranks'] == 1 and j['config']['points_per_gpu'] == n and j['config']['points_total'] == n
+    assert '1 active' in j['config']['parallelism']
+    assert j['exchange']['bytes_per_rank'] == {'allreduce': 0, 'p2p': 0}
+    assert abs(j['value'] - n * 3 / (j['ms_per_step'] * 3e-3)) <= 1e-6 * j['value']

@@ -377,3 +377,26 @@ def test_sharded_newton_processes_vs_reference_trace(fep, tmp_path, world, n_ste
         assert int(d['n_calls']) == int(np.load(tmp_path / 'rank0.npz')['n_calls'])
         n_pts += int(d['n_local_points'])
     assert n_pts == 800                                              # 20 x 20 cells x 2 triangles, every point on one rank
+
+
+@pytest.mark.gpu
+def test_newton_354_cells_regression_guard(fep):
+    """BASELINE configs[3]'s driver at 354 x 354 cells (250 632 P1 elements, 10 load steps) with the multigrid-CG solver and
+    two-digit linear solves — `tools/newton_bench.py --n 354 --inexact 1e-2` — against the pins of
+    tests/golden/newton_354_pins.json (written by tools/newton_pins.py, where the same history was also reached with
+    ten-digit solves: pressures equal to `max_rel_pressure_difference`): load history exact, footing pressures to 1e-7,
+    hot-path calls within 10 %, CG iterations within +50 % — so that later kernel work cannot break the end-to-end run
+    unnoticed (reference loop DP:1028-1131)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    pins = json.load(open(os.path.join(GOLDEN, 'newton_354_pins.json')))
+    want = pins['inexact_1e-2']
+    assert pins['max_rel_pressure_difference'] <= 1e-6
+    h = fep.solve_strip_footing('P1', n_cells=354, max_steps=10, linear_solver='amg', pcg_rtol=1e-10, pcg_inexact_rtol=1e-2,
+                                keep_U=False)
+    assert [float(z) for z in h['zeta']] == want['zeta'] and len(h['zeta']) == 10
+    got = np.array([float(p) for p in h['pressure']])
+    assert np.abs(got - np.array(want['pressure'])).max() <= 1e-7 * np.abs(want['pressure']).max()
+    assert abs(h['n_calls'] - want['hot_path_calls']) <= 0.1 * want['hot_path_calls']
+    assert sum(h['pcg_iters']) <= 1.5 * want['pcg_iters_total']

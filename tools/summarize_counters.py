@@ -18,18 +18,30 @@ def short(name):
 
 
 def kernel_stats(d):
-    """[(name, calls, total_ns, avg_ns, pct, min_ns, max_ns)] of one --stats pass."""
+    """[(name, calls, total_ns, avg_ns, pct, min_ns, max_ns, median_ns, steady_avg_ns)] of one --stats pass.  `steady_avg`
+    leaves out a kernel's FIRST launch when it has more than three (code load: round 4's Q2 pass held one 31.5 ms first call
+    among 43 of 0.5 ms); it is the figure the counter table divides by."""
     rows = []
     for f in glob.glob(os.path.join(d, '*', '*_kernel_stats.csv')):
         for r in csv.DictReader(open(f)):
-            rows.append((short(r['Name']), int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']),
-                         float(r['Percentage']), float(r['MinNs']), float(r['MaxNs'])))
+            calls, tot, mx = int(r['Calls']), float(r['TotalDurationNs']), float(r['MaxNs'])
+            steady = (tot - mx) / (calls - 1) if calls > 3 else tot / max(calls, 1)
+            rows.append((short(r['Name']), calls, tot, float(r['AverageNs']), float(r['Percentage']), float(r['MinNs']), mx,
+                         float('nan'), steady))
     for f in glob.glob(os.path.join(d, '*', '*.db')):
         c = sqlite3.connect(f)
         tot = c.execute('select sum(duration) from kernels').fetchone()[0] or 1.0
-        for name, n, t, a, lo, hi in c.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
-                                               'from kernels group by name order by sum(duration) desc'):
-            rows.append((short(name), n, float(t), float(a), 100.0 * t / tot, float(lo), float(hi)))
+        per = collections.defaultdict(list)
+        try:
+            cur = c.execute('select name, duration from kernels order by start')
+        except sqlite3.OperationalError:                 # (no `start` column in this rocpd version: launch order unknown)
+            cur = c.execute('select name, duration from kernels')
+        for name, dur in cur:
+            per[name].append(float(dur))
+        for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            srt = sorted(v)
+            steady = (sum(v) - srt[-1]) / (len(v) - 1) if len(v) > 3 else sum(v) / len(v)     # (the first launch is the longest one)
+            rows.append((short(name), len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, srt[0], srt[-1], srt[len(srt) // 2], steady))
     return rows
 
 
@@ -55,10 +67,10 @@ def main():
     rows = kernel_stats(os.path.join(base, 'stats'))
     with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w', newline='') as fh:
         w = csv.writer(fh)
-        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'MedianNs', 'AverageNsWithoutFirstLaunch'])
         for r in rows:
-            w.writerow([r[0], r[1], f'{r[2]:.0f}', f'{r[3]:.0f}', f'{r[4]:.2f}', f'{r[5]:.0f}', f'{r[6]:.0f}'])
-    avg = {r[0]: r[3] for r in rows}
+            w.writerow([r[0], r[1], f'{r[2]:.0f}', f'{r[3]:.0f}', f'{r[4]:.2f}', f'{r[5]:.0f}', f'{r[6]:.0f}', f'{r[7]:.0f}', f'{r[8]:.0f}'])
+    avg = {r[0]: r[8] for r in rows}                      # (steady-state average: without the first launch)
     allc = collections.defaultdict(dict)
     for sub in ('fetch', 'write', 'sq', 'sq2'):
         for k, cs in counters(os.path.join(base, sub)).items():
