@@ -50,7 +50,7 @@ struct fep_ctx {
                                                         // measured P2 / Q2 / P4 reduce kernel: 2: 0.406 / 0.376 / 0.654 ms, 4: 0.392 / 0.347 / 0.651,
                                                         // 6: 0.382 / 0.371 / 0.650, 8 (5 waves per SIMD): 0.432 / 0.425 / 0.733)
     bool kc_aos = false;                                // K_e half-blocks: all blocks of an element adjacent (AoS) or block-major (SoA)
-    // patch route of the element kernel (default; FEP_GEN_PATH=coo keeps the K_e round trip): fep_host.h, PatchPlan
+    // patch route of the element kernel (default; FEP_ROUTE=coo keeps the K_e round trip): fep_host.h, PatchPlan
     bool patch = false;
     int patch_eb = 0, patch_dbg = 0, patch_tpb = 256, patch_js = 1;   // workgroup shape of the patch form (ElemCfg)
     int lds_pad = 0;                                    // FEP_ELEM_LDS_PAD: extra LDS bytes per workgroup of element_kernel (occupancy experiments)
@@ -513,6 +513,11 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
     if (c->p1_node) {
         // gather plan of the node route (host, fep_host.h): tiles, staged element / node lists, codes, descriptors
         fep_host::P1Options opt;
+#ifdef FEP_ABLATION
+        // FEP_P1_TILE=128: tiles of 128 blocks on 128 threads (16 instead of 8 resident per CU; VERDICT r3 item 5's structural
+        // attempt: the K,F-only step measured 0.0706-0.0715 against 0.0629-0.0631 ms, profiles/r04_ablation.md)
+        if (const char* tl = fep_tune("FEP_P1_TILE")) c->tile = std::atoi(tl) == 128 ? 128 : 256;
+#endif
         opt.tile = c->tile;
 #ifdef FEP_ABLATION
         {   // FEP_P1_PATH=node_direct | node_list | node_unpacked | node2k: plans without one of the default's ingredients
@@ -801,9 +806,9 @@ extern "C" int fep_ctx_kernel_names(const fep_ctx* c, int which, char* buf, int6
     char tmp[256];
     if (c->p1_node && c->p1_lds) {
         if (which == 1 && c->p1_fused && c->fused_mode >= 1)
-            std::snprintf(tmp, sizeof tmp, "p1_fused_kernel<false, 256, %s, 1, 1, false, %s>", b(c->p1_fused_rng), b(c->p1_dma));
+            std::snprintf(tmp, sizeof tmp, "p1_fused_kernel<false, %d, %s, 1, 1, false, %s>", c->tile, b(c->p1_fused_rng), b(c->p1_dma));
         else
-            std::snprintf(tmp, sizeof tmp, "p1_point_kernel + p1_node_lds_kernel<256, %s, 1, %s>", b(c->p1_rng), b(c->p1_pk));
+            std::snprintf(tmp, sizeof tmp, "p1_point_kernel + p1_node_lds_kernel<%d, %s, 1, %s>", c->tile, b(c->p1_rng), b(c->p1_pk));
     } else if (c->p1_node) {
         std::snprintf(tmp, sizeof tmp, "p1_point_kernel + p1_node_kernel");
     } else if (c->gn) {
@@ -1079,6 +1084,9 @@ static int launch_p1_node(fep_ctx* c, hipStream_t st, const double* ds, const do
         if (c->lds_L > TPB) return FEP_ESTATE;          /* one staged element per lane (fep_host.h) */                  \
         if (c->p1_rng) NODE_LDS2(TPB, true, 1); else NODE_LDS2(TPB, false, 1);                                           \
     } while (0)
+#ifdef FEP_ABLATION
+            if (c->tile == 128) NODE_LDS(128); else
+#endif
             NODE_LDS(256);                 // tiles of 128 / 512 blocks were measured slower (profiles/r01_ablation.md)
 #undef NODE_LDS
 #undef NODE_LDS2
@@ -1164,12 +1172,12 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
 #else
 #define FUSED4(FULL, RNG, EPT, NPT)  FUSED5(FULL, RNG, EPT, NPT, false)
 #endif
-#define FUSED5(FULL, RNG, EPT, NPT, DMA)                                                                                 \
+#define FUSED6(FULL, RNG, EPT, NPT, DMA, TPB)                                                                                 \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void*)p1_fused_kernel<FULL, 256, RNG, EPT, NPT, false, DMA>,              \
+            HIP_TRY(hipFuncSetAttribute((const void*)p1_fused_kernel<FULL, TPB, RNG, EPT, NPT, false, DMA>,              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-        hipLaunchKernelGGL((p1_fused_kernel<FULL, 256, RNG, EPT, NPT, false, DMA>), dim3(8 * chunk), dim3(256), lds, st, \
+        hipLaunchKernelGGL((p1_fused_kernel<FULL, TPB, RNG, EPT, NPT, false, DMA>), dim3(8 * chunk), dim3(TPB), lds, st, \
                            c->n_e, c->lds_L, c->lds_C, c->lds_NL, c->perm_l, c->wg_elist, (const int4*)c->wg_rng,        \
                            c->wg_nlist, (const int4*)c->wg_nrng, c->el_nodes, c->pk, c->tdesc, c->xy,                   \
                            c->p1tab, u, e0, ep, c->shear, c->bulk, c->eta, c->c, c->matu, eout, s, ds, indp, k_data,      \
@@ -1177,8 +1185,13 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
                            (const double*)nullptr, (const double*)nullptr, 0, (const uint2*)nullptr,                     \
                            (unsigned long long*)nullptr);                                                                \
     } while (0)
-#define FUSED3(FULL, RNG) FUSED4(FULL, RNG, 1, 1)      /* L, NL <= 256 = threads: one staged element / node per lane (fep_host.h) */
-    if (c->lds_L > 256 || c->lds_NL > 256) return FEP_ESTATE;
+#ifdef FEP_ABLATION
+#define FUSED5(FULL, RNG, EPT, NPT, DMA) do { if (c->tile == 128) FUSED6(FULL, RNG, EPT, NPT, DMA, 128); else FUSED6(FULL, RNG, EPT, NPT, DMA, 256); } while (0)
+#else
+#define FUSED5(FULL, RNG, EPT, NPT, DMA) FUSED6(FULL, RNG, EPT, NPT, DMA, 256)
+#endif
+#define FUSED3(FULL, RNG) FUSED4(FULL, RNG, 1, 1)      /* L, NL <= threads: one staged element / node per lane (fep_host.h) */
+    if (c->lds_L > c->tile || c->lds_NL > c->tile) return FEP_ESTATE;
 #ifdef FEP_ABLATION
     if (full) { if (c->p1_fused_rng) FUSED3(true, true); else FUSED3(true, false); } else
 #else
@@ -1188,6 +1201,7 @@ static int launch_p1_fused(fep_ctx* c, hipStream_t st, const double* u, E0 e0, c
 #undef FUSED3
 #undef FUSED4
 #undef FUSED5
+#undef FUSED6
     HIP_TRY(hipGetLastError());
     if (counts_d) {
         hipLaunchKernelGGL(counts_finalize_kernel, dim3(1), dim3(256), 0, st, c->slot_counts, counts_d);

@@ -638,7 +638,7 @@ inline int validate_p1_plan(const P1Plan& P, const Symbolic& S, int64_t n_e, int
 }
 
 // ---------------------------------------------------------------------------------------
-// Opt-in node route of P2 / Q1 / Q2 (FEP_GEN_PATH=node): per tile of `tile` consecutive blocks the sorted unique
+// Node route of P2 / Q1 / Q2 (ablation build only, FEP_GEN_PATH=node): per tile of `tile` consecutive blocks the sorted unique
 // element list and 16-bit gather codes (local element << 8 | a << 4 | b).
 // ---------------------------------------------------------------------------------------
 struct GnPlan {
@@ -699,7 +699,7 @@ inline void build_gn_plan(const Symbolic& S, int n_p, int n_q, int64_t n_e, GnPl
 }
 
 // ---------------------------------------------------------------------------------------
-// Patch plan of the element route (P2 / Q1 / Q2 / P4, and P1 with FEP_P1_PATH=coo): the element matrices never make
+// Patch plan of the element route (P2 / Q1 / Q2 / P4, and P1 with FEP_ROUTE=patch): the element matrices never make
 // the round trip through HBM.
 //
 // A patch = the <= `eb` elements one workgroup of element_kernel processes: a chunk of the elements in the order of a
@@ -725,8 +725,8 @@ inline void build_gn_plan(const Symbolic& S, int n_p, int n_q, int64_t n_e, GnPl
 //   pel     eb int32 per patch: its elements, ascending, padded with -1;   pnodes  [patch][a][local element] node ids (0 padded)
 //   items   x: code offset in the patch:13 | (count-1):6 | degree of the row node:12 | open:1
 //           y: closed: position of the block's first row in double2 units (2*nptr[n] + slot); open: partial slot
-//   codes   uint16 (position of the stored block in LDS = idx*eb + local element) << 1 | transposed
-//   fitems  x: code offset:13 | (count-1):6 | open << 31;  y: node | force partial slot;   fcodes  a*eb + local element
+//   codes   uint16 (position of the stored block in the LDS image: patch_image_pos) << 1 | transposed
+//   fitems  x: code offset:13 | (count-1):6 | open << 31;  y: node | force partial slot;   fcodes  patch_force_pos
 //   fix     per upper open block: x = position (as items.y), y = degree | count << 16, z = first partial slot,
 //           w = second partial slot (count <= 2) or offset into plist (count > 2: `count` slots, ascending patch)
 //   fixT    its mirror: x = position of the transposed block (0xffffffff: diagonal block, no mirror), y = degree of ITS row node
@@ -753,6 +753,18 @@ struct PatchPlan {
     std::vector<U4> fix, ffix;
     std::vector<U2> fixT;
 };
+
+// Where the phase-3 LDS image keeps the stored block (j, a) of local element el, in 16-byte slots of a plane (fep_kernels.hip.h,
+// ElemCfg, uses the same formulas).  SKEWED: with the plain (j*n_p + a)*eb + el a step in a is eb slots and a step in j
+// n_p*eb slots — both multiples of 16 slots = the 256-byte bank row for every element type (eb is a multiple of 8, n_p*eb of
+// 16), so the gather of a CSR row's blocks, which walks j and a at fixed el, put all 16 lanes of a `ds_read_b128` group on ONE
+// slot (P4: 49 % of the LDS cycles were conflict cycles).  Odd element stride ebp = eb | 1, and one more slot per j when n_p
+// is even, make both steps odd.
+inline int patch_ebp(int eb) { return eb | 1; }
+inline int patch_image_period(int n_p, int eb) { return n_p * patch_ebp(eb) + ((n_p & 1) ? 0 : 1); }      // slots per j
+inline int patch_image_pos(int n_p, int eb, int j, int a, int el) { return j * patch_image_period(n_p, eb) + a * patch_ebp(eb) + el; }
+inline int patch_image_slots(int n_p, int eb) { return (n_p / 2 + 1) * patch_image_period(n_p, eb); }
+inline int patch_force_pos(int eb, int a, int el) { return a * patch_ebp(eb) + el; }
 
 // where element_kernel keeps the block (a, b) of K_e (same function as fep::sym_block_index, block-major numbering)
 inline void patch_block_index(int n_p, int a, int b, int& idx, bool& transposed) {
@@ -900,7 +912,7 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
     P = PatchPlan();
     P.eb = eb;
     const int nj = n_p / 2 + 1;
-    if (eb < 1 || (int64_t)n_p * n_p * eb > 8192 || (int64_t)nj * n_p * eb >= 32768) return FEP_OK;       // field widths: plan not usable
+    if (eb < 1 || (int64_t)n_p * n_p * eb > 8192 || patch_image_slots(n_p, eb) >= 32768) return FEP_OK;       // field widths: plan not usable
     const int64_t n_blk = (int64_t)S.ncol.size();
     std::vector<int32_t> patch_of;
     patch_grouping(S, n_p, n_e, n_n, elem, coords, eb, opt, P.pel, patch_of);
@@ -997,7 +1009,7 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
             for (int el = 0; el < nel; ++el)
                 for (int a = 0; a < n_p; ++a) {
                     const int32_t na = elem[(int64_t)a * n_e + pe[el]];
-                    ftup.push_back(Tup{na, (uint16_t)(a * eb + el)});
+                    ftup.push_back(Tup{na, (uint16_t)patch_force_pos(eb, a, el)});
                     const int32_t* row = S.ncol.data() + S.nptr[na];
                     const int32_t* row_end = S.ncol.data() + S.nptr[na + 1];
                     for (int b = 0; b < n_p; ++b) {
@@ -1005,7 +1017,7 @@ inline int build_patch_plan(const Symbolic& S, int n_p, int64_t n_e, int64_t n_n
                         const int32_t blk = (int32_t)(S.nptr[na] + (std::lower_bound(row, row_end, nb) - row));
                         int idx; bool tr;
                         patch_block_index(n_p, a, b, idx, tr);
-                        tup.push_back(Tup{blk, (uint16_t)(((idx * eb + el) << 1) | (tr ? 1 : 0))});
+                        tup.push_back(Tup{blk, (uint16_t)((patch_image_pos(n_p, eb, idx / n_p, idx % n_p, el) << 1) | (tr ? 1 : 0))});
                     }
                 }
             // (el, a, b) generation order = ascending element id: the stable sorts keep it inside every block / node
@@ -1209,8 +1221,9 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
             seq.clear();
             for (int k = 0; k < cnt; ++k) {
                 const unsigned code = P.codes[(size_t)d[2] + off + k];
-                const int pos = (int)(code >> 1), idx = pos / eb, el = pos % eb;
-                if (idx >= nj * n_p || el >= nel) return 6;
+                const int pos = (int)(code >> 1), per = patch_image_period(n_p, eb), ebp = patch_ebp(eb);
+                const int jj = pos / per, rem = pos % per, aa = rem / ebp, el = rem % ebp, idx = jj * n_p + aa;
+                if (jj >= nj || aa >= n_p || el >= nel || patch_image_pos(n_p, eb, jj, aa, el) != pos) return 6;
                 const int ab = ab_of[(size_t)2 * idx + (code & 1u)];
                 if (ab < 0) return 7;
                 seq.push_back((int32_t)((int64_t)ab * n_e + pe[el]));
@@ -1242,7 +1255,7 @@ inline int validate_patch_plan(const PatchPlan& P, const Symbolic& S, int n_p, i
             seq.clear();
             for (int k = 0; k < cnt; ++k) {
                 const unsigned code = P.fcodes[(size_t)d[6] + off + k];
-                const int a = (int)code / eb, el = (int)code % eb;
+                const int a = (int)code / patch_ebp(eb), el = (int)code % patch_ebp(eb);
                 if (a >= n_p || el >= nel) return 14;
                 seq.push_back((int32_t)((int64_t)a * n_e + pe[el]));
             }

@@ -359,7 +359,11 @@ template <int NP, int NQ, bool GEO = false, int TPB = kBlock, int JS = 1> struct
     static constexpr int kPts = (2 * NP + 9) * NPTS;
     static constexpr int kXY = 2 * NP * EB;             // one double2 per (local node, element)
     static constexpr int kTab = 2 * NP * NQ + NQ + (NQ & 1);
-    static constexpr int kKl = 4 * NJ * NP * EB, kFl = 2 * NP * EB;
+    // skewed image (fep_host.h: patch_image_pos): odd element stride, one more slot per j for even NP
+    static constexpr int EBP = EB | 1;
+    static constexpr int PER = NP * EBP + ((NP & 1) ? 0 : 1);      // slots per j
+    static constexpr int SLOTS = NJ * PER;                          // double2 per plane
+    static constexpr int kKl = 4 * SLOTS, kFl = 2 * NP * EBP;
     static constexpr int kCodes = (NP * NP * EB + 3) / 4 + 1, kFcodes = (NP * EB + 3) / 4 + 1;    // doubles holding the uint16 codes
     static constexpr int kPhase3 = kKl + kFl + kCodes + kFcodes;
 };
@@ -435,27 +439,55 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
 
     FEP_STAMP_P(pa, blockIdx.x, 0);
     __shared__ int32_t pel_s[PATCH ? EB : 1];
-    if (PATCH && t < EB) pel_s[t] = pa.pel[(int64_t)blockIdx.x * EB + t];
-    if (FROM_U || GEO) {
+    const int el1 = t / NQ, q1 = t - el1 * NQ;         // the lane's point in phase 1
+    // Patch form, 6- and 15-node triangles: the point's previous plastic strain is fetched through a chain of its own (element
+    // id -> ep) BESIDE the staging chain (node ids -> node data) instead of behind the barrier — one exposed round trip less
+    // at the top of phase 1: P2 -2.6...-5 %, P4 -2.5 % in one session.  Not for the quadrilaterals: Q2 +5.7 %, Q1 +3.5 % with it
+    // (all waves of the workgroup then sit at the barrier for both chains; behind the barrier each wave waits for its own
+    // loads and the waves drift apart, which is what overlaps them) — profiles/r04_ablation.md, section 2b.
+    constexpr bool HOIST = PATCH && FROM_U && (NP == 6 || NP == 15);
+    double pre_p[4] = {0.0, 0.0, 0.0, 0.0};            // (HOIST) the plastic strain, fetched beside the staging
+    if (PATCH) {
+        // Every load of the staging is unconditional at a clamped index — a load under a per-lane condition is waited for on
+        // the spot — and lanes outside a table's range drop what they fetched.
+        const int ts = t < NP * EB ? t : NP * EB - 1;
+        const int a = ts / EB, el = ts - a * EB;
+        const int elc = el1 < nel ? el1 : nel - 1;
+        const int32_t pe = pa.pel[(int64_t)blockIdx.x * EB + (t < EB ? t : EB - 1)];
+        int32_t nd = 0, e_pt = 0;
+        if (FROM_U || GEO) nd = pa.pnodes[((int64_t)blockIdx.x * NP + a) * EB + el];
+        if (HOIST && ep) e_pt = pa.pel[(int64_t)blockIdx.x * EB + elc];
+        double2 gxy = make_double2(0.0, 0.0), gu = make_double2(0.0, 0.0);
+        if (GEO) gxy = *reinterpret_cast<const double2*>(xy + 2 * (int64_t)nd);
+        if (FROM_U) gu = *reinterpret_cast<const double2*>(U + 2 * (int64_t)nd);
+        if (HOIST && ep) {
+            const unsigned kb = ((unsigned)e_pt * NQ + q1) * 8u;
+            pre_p[0] = ld_row(ep, n_int, 0, kb); pre_p[1] = ld_row(ep, n_int, 1, kb); pre_p[2] = ld_row(ep, n_int, 2, kb); pre_p[3] = ld_row(ep, n_int, 3, kb);
+        }
+        if (t < EB) pel_s[t] = pe;
+        if (t < NP * EB) {
+            if (GEO) cxy[a][el] = gxy;
+            if (FROM_U) cu[a][el] = gu;
+        }
+    } else if (FROM_U || GEO) {
         if (t < NP * EB) {
             const int a = t / EB, el = t - a * EB;
-            const int64_t nd = PATCH ? pa.pnodes[((int64_t)blockIdx.x * NP + a) * EB + el]
-                                     : (el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0);
+            const int64_t nd = el < nel ? elem[(int64_t)a * n_e + e0blk + el] : 0;
             if (GEO) cxy[a][el] = *reinterpret_cast<const double2*>(xy + 2 * nd);
             if (FROM_U) cu[a][el] = *reinterpret_cast<const double2*>(U + 2 * nd);
         }
-        if (GEO) {
-            for (int i = t; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
-            for (int i = t; i < NQ; i += TPB) tw[i] = wf[i];
-        }
+    }
+    if (GEO) {
+        for (int i = t; i < NP * NQ; i += TPB) { t1[i] = dh1[i]; t2[i] = dh2[i]; }
+        for (int i = t; i < NQ; i += TPB) tw[i] = wf[i];
     }
     if (FROM_U || GEO || PATCH) __syncthreads();
     FEP_STAMP_P(pa, blockIdx.x, 1);                                                  // node data staged
 
-    // ---- phase 1 (one pass: EB * NQ <= TPB).  The point's operand loads are issued here, after the barrier: hoisting
-    // them (and the patch tables) in front of it was measured 7-15 % slower — the waves of a workgroup then wait in step.
+    // ---- phase 1 (one pass: EB * NQ <= TPB).  The point's operand loads are issued here, after the barrier (but for the
+    // plastic strain of the triangles, HOIST above): hoisting all of them and the patch tables in front of it was measured
+    // 7-15 % slower in round 3 — the waves of a workgroup then wait in step.
     int branch = 0;
-    const int el1 = t / NQ, q1 = t - el1 * NQ;
     if (t < EB * NQ && el1 < nel) {
         const int el = el1, q = q1;
         const int64_t k = PATCH ? (int64_t)pel_s[el] * NQ + q : e0blk * NQ + t;
@@ -467,7 +499,7 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         // loads in flight per lane; the 15-node element takes 5 at a time (its 512-thread form must stay within 128 VGPRs).
         // The strain is written out in fused multiply-adds: which of two products the compiler fuses is its choice, and it
         // chose differently in the 256- and the 512-thread instantiation (point outputs differed in the last bit).
-        constexpr int CH = NP == 15 ? 5 : NP;
+        constexpr int CH = (NP == 15 && TPB == 512) ? 5 : NP;       // (one round trip instead of three where the registers allow)
         if (GEO) {
             double g1[NP], g2[NP];
             double x[NP], y[NP];
@@ -507,7 +539,10 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         double s[4], d[6];
         if (FROM_U) {
             double p[4] = {0.0, 0.0, 0.0, 0.0};
-            if (ep) { p[0] = ld_row(ep, n_int, 0, kb); p[1] = ld_row(ep, n_int, 1, kb); p[2] = ld_row(ep, n_int, 2, kb); p[3] = ld_row(ep, n_int, 3, kb); }
+            if (ep) {
+                if (HOIST) { p[0] = pre_p[0]; p[1] = pre_p[1]; p[2] = pre_p[2]; p[3] = pre_p[3]; }
+                else { p[0] = ld_row(ep, n_int, 0, kb); p[1] = ld_row(ep, n_int, 1, kb); p[2] = ld_row(ep, n_int, 2, kb); p[3] = ld_row(ep, n_int, 3, kb); }
+            }
             const double m_sh = mu.on ? mu.shear : ld_row(shear, 0, 0, kb), m_bu = mu.on ? mu.bulk : ld_row(bulk, 0, 0, kb);
             const double m_eta = mu.on ? mu.eta : ld_row(eta, 0, 0, kb), m_c = mu.on ? mu.c : ld_row(cc, 0, 0, kb);
             branch = dp_return_map(ev, e0.v, p, m_sh, m_bu, m_eta, m_c, accept != 0, s, d);
@@ -603,10 +638,10 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
     }
 
     // ---- phase 3 (patch route) --------------------------------------------------------
-    // stored block (idx, el): first row at Kr0[idx * EB + el], second row at Kr1[idx * EB + el] (two planes, see ElemCfg)
+    // stored block (j, a, el): first row at Kr0[pos], second row at Kr1[pos], pos = j*PER + a*EBP + el (two planes, skewed: ElemCfg)
     double2* Kr0 = reinterpret_cast<double2*>(lds);
-    double2* Kr1 = Kr0 + NJ * NP * EB;
-    double2* fl2 = reinterpret_cast<double2*>(lds + C::kKl);           // force pair (a, el) at [a * EB + el]
+    double2* Kr1 = Kr0 + C::SLOTS;
+    double2* fl2 = reinterpret_cast<double2*>(lds + C::kKl);           // force pair (a, el) at [a * EBP + el]
     const uint16_t* codes_l = reinterpret_cast<const uint16_t*>(codes32);
     const uint16_t* fcodes_l = reinterpret_cast<const uint16_t*>(fcodes32);
     // Phase 3's tables, fetched behind phase 2 — EVERY item descriptor of the patch (at most NP*NP*EB of them), so that phase 3
@@ -659,11 +694,11 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             const int jj = j0 + j;
             if (JS > 1 && jj >= NJ) continue;
             if (NP % 2 == 0 && jj == NP / 2 && a >= NP / 2) continue;
-            const int pos = (jj * NP + a) * EB + el;
+            const int pos = jj * C::PER + a * C::EBP + el;
             Kr0[pos] = make_double2(kk[j][0], kk[j][1]);
             Kr1[pos] = make_double2(kk[j][2], kk[j][3]);
         }
-        if (JS == 1 || h == 0) fl2[a * EB + el] = make_double2(f0, f1);
+        if (JS == 1 || h == 0) fl2[a * C::EBP + el] = make_double2(f0, f1);
     }
 #pragma unroll
     for (int r = 0; r < CWPT; ++r) { const int i = r * TPB + t; if (i < (n_codes + 1) / 2) codes32[i] = cpre[r]; }

@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
             }
         }
     }
-    // patch plans of the element route (every element type runs it; P1 with FEP_P1_PATH=coo), at the kernels' patch sizes
+    // patch plans of the element route (every element type runs it; P1 with FEP_ROUTE=patch | coo), at the kernels' patch sizes
     // and at odd ones, both groupings (consecutive elements / Hilbert curve through the centroids; a mesh file without
     // coordinates: node id -> a point of a 2-D lattice stands in) and both classifications of open blocks;
     // replayed against the symbolic phase contribution by contribution
