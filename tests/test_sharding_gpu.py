@@ -273,3 +273,83 @@ def test_host_tensors_never_reach_an_rccl_all_reduce(monkeypatch):
     dn._allreduce_(d)                                                 # gloo: device tensors through the host
     dn._allreduce_(h)
     assert seen == ['cpu', 'cpu']
+
+
+def test_iface_sum_kernel_is_the_host_rank_order_sum(fep):
+    """fep_iface_sum_f64 (last step of the neighbour-only exchange) against Partition._iface_sum_host on the index tables of
+    a real partition: a rank of a world of 3 on a mesh whose cuts meet (nodes with two AND with three holders), random local
+    force and random received values; bit for bit (0 + c_a + c_b + ... in ascending rank order on both sides)."""
+    import torch
+    from importlib import import_module
+    _lib = import_module('fem-elastoplasticity_amd._lib')
+    mesh = fep.rect_mesh(9, 7, 'P1', 10, 10)
+    rng = np.random.default_rng(11)
+    elem = mesh['elements'][:, rng.permutation(mesh['elements'].shape[1])]       # scattered ranges: many shared nodes, 3 holders too
+    n_n = mesh['coordinates'].shape[1]
+    part = fep.Partition(elem, n_n, 1, 3, exchange='p2p')
+    assert part.p2p_ranks == [0, 2] and (part.mult == 3).any() and (part.mult == 2).any()
+    F = rng.normal(size=2 * part.nodes.size)
+    recv = rng.normal(size=part.p2p_send_dofs.size)
+    want = F.copy()
+    part._iface_sum_host(want, recv)
+    dev = torch.device('cuda', 0)
+    Fd = torch.from_numpy(F.copy()).to(dev)
+    Rd = torch.from_numpy(recv).to(dev)
+    loc = torch.from_numpy(part.iface_local_dofs.astype(np.int32)).to(dev)
+    ptr = torch.from_numpy(part.p2p_ptr).to(dev)
+    src = torch.from_numpy(part.p2p_src).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().fep_iface_sum_f64(0, st, loc.numel(), loc.data_ptr(), ptr.data_ptr(), src.data_ptr(), Rd.data_ptr(),
+                                            Fd.data_ptr()), 'fep_iface_sum_f64')
+    got = Fd.cpu().numpy()
+    assert np.array_equal(got, want)
+    inner = np.ones(F.size, dtype=bool)
+    inner[part.iface_local_dofs] = False
+    assert np.array_equal(got[inner], F[inner])                                 # DOFs off the interface are not touched
+    assert _lib.lib().fep_iface_sum_f64(0, st, 0, None, None, None, None, None) == 0          # n = 0: nothing to do
+    assert _lib.lib().fep_iface_sum_f64(0, st, 4, None, ptr.data_ptr(), src.data_ptr(), Rd.data_ptr(), Fd.data_ptr()) == -1
+
+
+def test_gated_shards_on_the_device(fep):
+    """min_elements_per_rank on ShardedContext: the ranks that take elements reproduce the global step between them, a rank
+    left idle holds no context and its exchange calls return at once."""
+    import torch
+    mesh = fep.rect_mesh(20, 30, 'P1', 10, 15)                                 # 1 200 elements
+    elem, coord = mesh['elements'], mesh['coordinates']
+    with pytest.warns(UserWarning):
+        shards = [fep.ShardedContext(elem, coord, r, 4, min_elements_per_rank=500) for r in range(4)]     # 1200 // 500 = 2 ranks
+    assert [s.active for s in shards] == [True, True, False, False] and all(s.gated and s.active_world == 2 for s in shards)
+    assert shards[2].ctx is None and shards[3].ctx is None and shards[0].n_iface == 21
+    plain = [fep.ShardedContext(elem, coord, r, 2) for r in range(2)]
+    for a, b in zip(shards[:2], plain):
+        assert np.array_equal(a.nodes, b.nodes) and np.array_equal(a.local_elements, b.local_elements) and (a.lo, a.hi) == (b.lo, b.hi)
+    idle = shards[3]
+    F = torch.zeros(0, dtype=torch.float64, device='cuda:0')
+    assert idle.exchange_force_(F, mode='p2p') is F                             # no neighbours: nothing is sent
+    idle.set_materials(1.0, 1.0, 1.0, 1.0)                                      # (no context: a no-op)
+    assert idle.local_point_slice() == slice(0, 0)
+    for s in shards + plain:
+        s.close()
+
+
+@pytest.mark.parametrize('t,n,pattern', [('P1', 20, 'p1_point_kernel + p1_node_lds_kernel<256, '), ('P2', 10, 'element_kernel<6, 7, true, true, true, 512, 1> + fixup_kernel'),
+                                         ('Q1', 12, 'element_kernel<4, 4, true, true, true, 256, 1> + fixup_kernel'),
+                                         ('Q2', 8, 'element_kernel<8, 9, true, true, true, 256, 1> + fixup_kernel')])
+def test_kernel_names_are_what_the_profiler_prints(fep, t, n, pattern):
+    """fep_ctx_kernel_names: the names bench.py labels its roofline with and checks profiles/traffic_latest.json against
+    (the committed rocprofv3 summaries profiles/r04_*_kernel_stats.csv carry exactly these strings)."""
+    mesh = fep.square_mesh(n, t, 10)
+    ctx = fep.MeshContext(mesh['elements'], mesh['coordinates'])
+    full, kf = ctx.kernel_names(0), ctx.kernel_names(1)
+    assert full.startswith(pattern), full
+    if t == 'P1':
+        assert kf.startswith('p1_fused_kernel<false, 256, ') and kf.endswith(', 1, 1, false, false>'), kf
+        import csv, os
+        from conftest import ROOT
+        stats = {r['Name'] for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04_p1_kernel_stats.csv')))}
+        if ctx.kernel_names(0).endswith('<256, true, 1, true>'):                # (a structured mesh: the run-table form, as bench.py's)
+            assert set(full.split(' + ')) <= stats and kf in stats
+    else:
+        assert kf == full
+    assert not fep.lib().fep_build_is_ablation() or os.environ.get('FEP_LIB_PATH')        # the default library is the product build
+    ctx.close()
