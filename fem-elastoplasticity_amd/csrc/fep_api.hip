@@ -454,7 +454,7 @@ extern "C" int fep_ctx_create(fep_ctx** ctx_out, int device_id, int elem_type, i
 
 // The element kernel's per-type choices (measured; the notes are at their use in ctx_create_impl)
 static constexpr bool elem_geo_default(int elem_type, bool patch_form) {
-    return elem_type == FEP_Q1 || elem_type == FEP_Q2 || (elem_type == FEP_P2 && patch_form);
+    return elem_type == FEP_Q1 || elem_type == FEP_Q2 || ((elem_type == FEP_P2 || elem_type == FEP_P4) && patch_form);
 }
 static void patch_shape_default(int elem_type, bool patch_form, int& tpb, int& js) {
     tpb = 256; js = 1;
@@ -617,7 +617,9 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
         // 0.218 ms) and Q2 (0.344 vs 0.391 ms with 24 instead of 28 elements per workgroup, so that three workgroups still fit a
         // CU) and loses for P2 in the COO form (0.50 vs 0.47 ms at 28 / 32 elements per workgroup); round 3, patch form:
         // recomputed geometry wins for P2 as well (same session, 1 M elements: 0.754 vs 0.783 ms on a fast box, 0.888 vs 0.936
-        // on a slow one)
+        // on a slow one); round 4, final patch kernel, one session, two passes each: P4 0.769-0.771 against 0.842-0.869 ms (its 30
+        // gradient loads per point were a third of its workgroup's life), Q2 0.604 / 0.709, P2 0.632-0.638 / 0.700-0.710, Q1
+        // 0.163-0.164 / 0.167-0.174: recomputed for every type in the patch form
         c->elem_geo = elem_geo_default(elem_type, want_patch);
 #ifdef FEP_ABLATION
         if (const char* ge = fep_tune("FEP_ELEM_GEO")) c->elem_geo = std::strcmp(ge, "0") != 0;
