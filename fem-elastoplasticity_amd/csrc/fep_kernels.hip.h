@@ -16,12 +16,12 @@ namespace fep {
 
 constexpr int kBlock = 256;
 
-// -DFEP_P2_FMA=1: phase 2 of element_kernel with every product fused into its accumulator (57 instead of 84 vector
-// instructions per point and lane; K differs in the last bits).  Measured in one session against the default: P2 1 M elements
-// +2 % (0.700 against 0.686 ms), Q2 +2.5 %, P4 / Q1 equal, BASELINE configs[4] -2.5 %: the arithmetic of phase 2 is not what
-// the kernel waits for.  Off.
+// FEP_P2_FMA: phase 2 of element_kernel with every product fused into its accumulator (57 instead of 84 vector instructions per
+// point and lane; K differs in the last bits from the multiply / multiply-add / add form, -DFEP_P2_FMA=0).  Round 3 measured it
+// even (P2 +2 %, Q2 +2.5 %, configs[4] -2.5 %: the kernel then waited for loads it no longer waits for); on round 4's kernel, one
+// session, four passes each (profiles/r04_ablation.md section 2d): P4 0.734 against 0.779 ms, Q2 0.538 / 0.582, P2 0.600 / 0.611.  On.
 #ifndef FEP_P2_FMA
-#define FEP_P2_FMA 0
+#define FEP_P2_FMA 1
 #endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding global stores
