@@ -380,13 +380,16 @@ struct PatchArgs {
     double* Pc; double* Pf;                             // partial blocks (4 doubles per slot) / partial forces (2)
     double* data; double* F;                            // CSR values / nodal force (either may be NULL)
 #ifdef FEP_ABLATION
-    unsigned long long* clk;                            // FEP_PHASE_CLK: 8 shader-clock stamps per workgroup (thread 0), or NULL
+    unsigned long long* clk;                            // FEP_PHASE_CLK: 10 stamps per workgroup (thread 0), or NULL: [0..6] s_memtime (shader
+                                                        // clock) at the phase boundaries, [8], [9] s_memrealtime (100 MHz) at start / end
 #endif
 };
 
 // Phase stamps of the ablation build (thread 0 of every workgroup; the barriers keep the waves of a workgroup in step)
 #ifdef FEP_ABLATION
-#define FEP_STAMP_P(pa, p, i) do { if ((pa).clk && threadIdx.x == 0) (pa).clk[(size_t)(p) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FEP_STAMP_P(pa, p, i) do { if ((pa).clk && threadIdx.x == 0) { (pa).clk[(size_t)(p) * 10 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if ((i) == 0) (pa).clk[(size_t)(p) * 10 + 8] = __builtin_amdgcn_s_memrealtime();                                    \
+        if ((i) == 6) (pa).clk[(size_t)(p) * 10 + 9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define FEP_STAMP_P(pa, p, i) do { } while (0)
 #endif
