@@ -1293,9 +1293,26 @@ extern "C" int fep_step_dev(fep_ctx* c, void* stream, const double* u_d, const d
     FEP_TRY((launch_element<NP, NQ, true>(c, st, u_d, e0, ep_prev_d, accept, e_out_d, s_d, ds_d, ind_p_d, blk, \
                                           c->patch ? k_data_d : (k_data_d ? c->Kc : nullptr),            \
                                           c->patch ? f_out_d : (f_out_d ? c->fe : nullptr))))
+    bool counted = false;
+#ifdef FEP_ABLATION
+    // FEP_FIX_SIDE=1 — an UPPER BOUND, not a route: fixup_kernel on a side stream, NOT ordered behind this call's element kernel (it
+    // adds whatever partials the call before left; K's open blocks are stale), joined at the end: what a perfectly overlapped
+    // fix-up could save
+    if (c->patch && fep_tune("FEP_FIX_SIDE")) {
+        static hipStream_t side = nullptr;
+        static hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (!side) { HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(ev_a, st));
+        HIP_TRY(hipStreamWaitEvent(side, ev_a, 0));
+        FEP_TRY(launch_fixup(c, side, k_data_d, f_out_d, cnt, &counted));
+        HIP_TRY(hipEventRecord(ev_b, side));
+        DISPATCH_ELEM(c->elem_type, CALL)
+        HIP_TRY(hipStreamWaitEvent(st, ev_b, 0));
+        return counted ? FEP_OK : launch_counts(c, st, cnt);
+    }
+#endif
     DISPATCH_ELEM(c->elem_type, CALL)
 #undef CALL
-    bool counted = false;
     if (c->patch) FEP_TRY(launch_fixup(c, st, k_data_d, f_out_d, cnt, &counted));
     else FEP_TRY(launch_reduce(c, st, k_data_d, f_out_d, cnt, &counted));
     return counted ? FEP_OK : launch_counts(c, st, cnt);

@@ -72,4 +72,7 @@ print(f'{t}{" K/F-only" if kf_only else ""} N={N} n_e={ctx.n_e} n_int={n} nnz={c
       f'step {dt*1e3:.3f} ms -> {n/dt/1e9:.2f} G upd/s | kernels ms {({k: round(v, 4) for k, v in kms.items()})} | '
       f'alg {alg/1e6:.0f} MB -> element kernel {alg/(kms["element"]*1e-3)/1e12:.2f} TB/s, '
       f'whole step {alg/dt/1e12:.2f} TB/s')
+if os.environ.get('FEP_BENCH_HASH'):        # bitwise comparison of K and F between libraries (same inputs): one digest per run
+    import hashlib
+    print('  sha1 K', hashlib.sha1(Kd.cpu().numpy().tobytes()).hexdigest()[:16], 'F', hashlib.sha1(F.cpu().numpy().tobytes()).hexdigest()[:16])
 ctx.close()                         # (the ablation build reports its phase clocks when the context is destroyed)
