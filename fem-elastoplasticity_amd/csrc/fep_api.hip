@@ -395,17 +395,20 @@ extern "C" int fep_ctx_destroy(fep_ctx* c) {
     if (fep_set_device(c->device) == FEP_OK) {
 #ifdef FEP_ABLATION
         if (c->phase_clk && c->n_patch > 0) {            // mean shader clocks per phase of the LAST element_kernel launch
-            std::vector<unsigned long long> h((size_t)(10 * c->n_patch));
+            std::vector<unsigned long long> h((size_t)(12 * c->n_patch));
             if (hipDeviceSynchronize() == hipSuccess &&
                 hipMemcpy(h.data(), c->phase_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                double acc[6] = {0, 0, 0, 0, 0, 0}, cyc = 0.0, real = 0.0;
+                double acc[6] = {0, 0, 0, 0, 0, 0}, cyc = 0.0, real = 0.0, st_ids = 0.0, st_data = 0.0, st_bar = 0.0;
                 unsigned long long lo = ~0ull, hi = 0;
                 for (int64_t p = 0; p < c->n_patch; ++p) {
-                    const unsigned long long* s = h.data() + 10 * p;
+                    const unsigned long long* s = h.data() + 12 * p;
                     for (int k = 0; k < 6; ++k) acc[k] += (double)(s[k + 1] - s[k]);
                     lo = std::min(lo, s[0]); hi = std::max(hi, s[6]);
                     cyc += (double)(s[6] - s[0]); real += (double)(s[9] - s[8]);
+                    st_ids += (double)(s[10] - s[0]); st_data += (double)(s[11] - s[10]); st_bar += (double)(s[1] - s[11]);
                 }
+                std::fprintf(stderr, "[fep] staging of thread 0's wave: ids %.0f, node data %.0f, LDS writes + barrier (the other waves) %.0f\n",
+                             st_ids / c->n_patch, st_data / c->n_patch, st_bar / c->n_patch);
                 std::fprintf(stderr, "[fep] phase clocks, mean per workgroup of %lld (stage, phase1, phase2, wait, image, phase3): "
                              "%.0f %.0f %.0f %.0f %.0f %.0f  sum %.0f; first start -> last end %llu; shader clock %.0f MHz (s_memtime / s_memrealtime x 100 MHz over the workgroups)\n", (long long)c->n_patch,
                              acc[0] / c->n_patch, acc[1] / c->n_patch, acc[2] / c->n_patch, acc[3] / c->n_patch, acc[4] / c->n_patch,
@@ -718,8 +721,8 @@ static int ctx_create_impl(fep_ctx*& c, fep_ctx** ctx_out, int device_id, int el
                 CK(upload(&c->pt_plist, P.plist.data(), (int64_t)P.plist.size()));
 #ifdef FEP_ABLATION
                 if (fep_tune("FEP_PHASE_CLK")) {
-                    CK(dmalloc(&c->phase_clk, 10 * P.n_patch));
-                    if (r == FEP_OK) (void)hipMemset(c->phase_clk, 0, (size_t)(10 * P.n_patch) * sizeof(unsigned long long));
+                    CK(dmalloc(&c->phase_clk, 12 * P.n_patch));
+                    if (r == FEP_OK) (void)hipMemset(c->phase_clk, 0, (size_t)(12 * P.n_patch) * sizeof(unsigned long long));
                 }
 #endif
                 CK(dmalloc(&c->Pc, 4 * P.n_part));

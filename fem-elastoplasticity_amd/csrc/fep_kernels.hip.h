@@ -387,9 +387,9 @@ struct PatchArgs {
 
 // Phase stamps of the ablation build (thread 0 of every workgroup; the barriers keep the waves of a workgroup in step)
 #ifdef FEP_ABLATION
-#define FEP_STAMP_P(pa, p, i) do { if ((pa).clk && threadIdx.x == 0) { (pa).clk[(size_t)(p) * 10 + (i)] = __builtin_amdgcn_s_memtime(); \
-        if ((i) == 0) (pa).clk[(size_t)(p) * 10 + 8] = __builtin_amdgcn_s_memrealtime();                                    \
-        if ((i) == 6) (pa).clk[(size_t)(p) * 10 + 9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define FEP_STAMP_P(pa, p, i) do { if ((pa).clk && threadIdx.x == 0) { (pa).clk[(size_t)(p) * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if ((i) == 0) (pa).clk[(size_t)(p) * 12 + 8] = __builtin_amdgcn_s_memrealtime();                                    \
+        if ((i) == 6) (pa).clk[(size_t)(p) * 12 + 9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define FEP_STAMP_P(pa, p, i) do { } while (0)
 #endif
@@ -460,6 +460,9 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
         int32_t nd = 0, e_pt = 0;
         if (FROM_U || GEO) nd = pa.pnodes[((int64_t)blockIdx.x * NP + a) * EB + el];
         if (HOIST && ep) e_pt = pa.pel[(int64_t)blockIdx.x * EB + elc];
+#ifdef FEP_ABLATION
+        if (pa.clk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FEP_STAMP_P(pa, blockIdx.x, 10); }   // the ids have arrived
+#endif
         double2 gxy = make_double2(0.0, 0.0), gu = make_double2(0.0, 0.0);
         if (GEO) gxy = *reinterpret_cast<const double2*>(xy + 2 * (int64_t)nd);
         if (FROM_U) gu = *reinterpret_cast<const double2*>(U + 2 * (int64_t)nd);
@@ -467,6 +470,9 @@ element_kernel(int64_t n_e, const int32_t* __restrict__ elem,
             const unsigned kb = ((unsigned)e_pt * NQ + q1) * 8u;
             pre_p[0] = ld_row(ep, n_int, 0, kb); pre_p[1] = ld_row(ep, n_int, 1, kb); pre_p[2] = ld_row(ep, n_int, 2, kb); pre_p[3] = ld_row(ep, n_int, 3, kb);
         }
+#ifdef FEP_ABLATION
+        if (pa.clk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FEP_STAMP_P(pa, blockIdx.x, 11); }   // the node data (and the plastic strain) too
+#endif
         if (t < EB) pel_s[t] = pe;
         if (t < NP * EB) {
             if (GEO) cxy[a][el] = gxy;
